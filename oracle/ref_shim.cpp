@@ -1,0 +1,197 @@
+/*
+ * ref_shim.cpp -- extern "C" doorway into the REAL reference, compiled where it
+ * lies under /root/reference (see oracle/Makefile target `ref`).  The reference
+ * has C++ linkage and no main(); this file only forwards calls so that tests
+ * and the golden-vector generator can reach it through ctypes.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Output goes to oracle/_ref/ (git-ignored).  No
+ * reference source is copied: this file #includes the reference headers from
+ * /root/reference/inc at build time and holds loops of our own only where the
+ * reference has none (motion search: SURVEY.md App. A.7 over the reference's
+ * own xSadN[]; frame-level TQ: the per-CU call sequence of
+ * src/encode.cpp:868-925 over a TU grid).
+ */
+#include "x265.h"
+#include "md5.h"
+
+#include <string.h>
+
+extern "C" {
+
+struct ref_mv {
+    int16_t mvx, mvy;
+    uint32_t sad;
+};
+
+const int8_t *ref_dct_matrix(int n)
+{
+    switch (n) {
+    case 4: return (const int8_t *)g_aiT4;
+    case 8: return (const int8_t *)g_aiT8;
+    case 16: return (const int8_t *)g_aiT16;
+    default: return (const int8_t *)g_aiT32;
+    }
+}
+int ref_chroma_qp(int qp) { return g_aucChromaScale[qp]; }
+int ref_quant_scale(int i) { return g_quantScales[i]; }
+int ref_inv_quant_scale(int i) { return g_invQuantScales[i]; }
+
+uint32_t ref_sad(int w, int n, const uint8_t *src, int ss, const uint8_t *ref, int sr)
+{
+    return xSadN[xLog2(w - 1) - 2](n, src, ss, ref, sr);
+}
+void ref_fwd_1d(int idx, int16_t *dst, int16_t *src, unsigned stride, int lines, int shift)
+{
+    xDctN[idx](dst, src, stride, lines, shift);
+}
+void ref_inv_1d(int idx, int16_t *dst, int16_t *src, unsigned stride, int lines, int shift)
+{
+    xInvDctN[idx](dst, src, stride, lines, shift);
+}
+void ref_sub_dct(int16_t *dst, uint8_t *src, uint8_t *ref, unsigned stride, int16_t *t0,
+                 int16_t *t1, int w, int h, unsigned mode)
+{
+    xSubDct(dst, src, ref, stride, t0, t1, w, h, mode);
+}
+void ref_idct_add(uint8_t *dst, int16_t *src, uint8_t *ref, unsigned stride, int16_t *t0,
+                  int16_t *t1, int w, int h, unsigned mode)
+{
+    xIDctAdd(dst, src, ref, stride, t0, t1, w, h, mode);
+}
+uint32_t ref_quant(int16_t *dst, int16_t *src, unsigned stride, unsigned qp, int w, int h, int st)
+{
+    return xQuant(dst, src, stride, qp, w, h, (X265_SliceType)st);
+}
+void ref_dequant(int16_t *dst, int16_t *src, unsigned stride, unsigned qp, int w, int h, int st)
+{
+    xDeQuant(dst, src, stride, qp, w, h, (X265_SliceType)st);
+}
+
+/* Exhaustive search over the reference's xSadN[] with the reference's argmin
+ * idiom (src/encode.cpp:725-727,762-765). */
+void ref_me_fullsearch(const uint8_t *cur, const uint8_t *ref, int width, int height, int stride,
+                       int ctu, int range, ref_mv *out, int first_ctu, int step, int count,
+                       int nthreads)
+{
+    const int ncx = width / ctu, ncy = height / ctu, nctu = ncx * ncy;
+    xSad *sad = xSadN[xLog2(ctu - 1) - 2];
+    if (step < 1) step = 1;
+    if (count < 0) count = (nctu - first_ctu + step - 1) / step;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int i = 0; i < count; i++) {
+        int idx = first_ctu + i * step;
+        if (idx >= nctu) continue;
+        const int cx = (idx % ncx) * ctu, cy = (idx / ncx) * ctu;
+        UInt32 best = MAX_SAD;
+        int bx = 0, by = 0;
+        for (int dy = -range; dy <= range; dy++) {
+            if (cy + dy < 0 || cy + dy + ctu > height) continue;
+            for (int dx = -range; dx <= range; dx++) {
+                if (cx + dx < 0 || cx + dx + ctu > width) continue;
+                UInt32 c = sad(ctu, cur + (size_t)cy * stride + cx, stride,
+                               ref + (size_t)(cy + dy) * stride + cx + dx, stride);
+                if (c < best) {
+                    best = c;
+                    bx = dx;
+                    by = dy;
+                }
+            }
+        }
+        out[idx].mvx = (int16_t)bx;
+        out[idx].mvy = (int16_t)by;
+        out[idx].sad = best;
+    }
+}
+
+static void fetch(uint8_t *d, const uint8_t *p, int ps, const ref_mv *mv, int mv_ctu, int ncx,
+                  int x0, int y0, int n)
+{
+    int ox = 0, oy = 0;
+    if (mv) {
+        ox = mv[(y0 / mv_ctu) * ncx + x0 / mv_ctu].mvx;
+        oy = mv[(y0 / mv_ctu) * ncx + x0 / mv_ctu].mvy;
+    }
+    for (int i = 0; i < n; i++) memcpy(d + i * MAX_CU_SIZE, p + (size_t)(y0 + oy + i) * ps + x0 + ox, n);
+}
+
+/* Per-TU xSubDct + xQuant, then (optionally) xDeQuant + xIDctAdd, with the
+ * reference's own scratch layout (stride MAX_CU_SIZE, in-place tmp0) */
+void ref_tq_frame(const uint8_t *src, int sstride, const uint8_t *pred, int pstride,
+                  const ref_mv *mv, int mv_ctu, int width, int height, int n, int qp, int st,
+                  const uint8_t *modes, int16_t *level, int cstride, uint32_t *abs_sum,
+                  uint8_t *rec, int rstride)
+{
+    const int ntx = width / n, nty = height / n, ncx = mv ? width / mv_ctu : 0;
+    UInt8 s[MAX_CU_SIZE * MAX_CU_SIZE], p[MAX_CU_SIZE * MAX_CU_SIZE], r[MAX_CU_SIZE * MAX_CU_SIZE];
+    Int16 t0[MAX_CU_SIZE * MAX_CU_SIZE], t1[MAX_CU_SIZE * MAX_CU_SIZE], q[MAX_CU_SIZE * MAX_CU_SIZE];
+    for (int ty = 0; ty < nty; ty++)
+        for (int tx = 0; tx < ntx; tx++) {
+            const int x0 = tx * n, y0 = ty * n;
+            for (int i = 0; i < n; i++) memcpy(s + i * MAX_CU_SIZE, src + (size_t)(y0 + i) * sstride + x0, n);
+            fetch(p, pred, pstride, mv, mv_ctu, ncx, x0, y0, n);
+            UInt mode = modes ? modes[ty * ntx + tx] : MODE_INVALID;
+            xSubDct(t0, s, p, MAX_CU_SIZE, t0, t1, n, n, mode);
+            UInt32 sum = xQuant(q, t0, MAX_CU_SIZE, qp, n, n, (X265_SliceType)st);
+            if (abs_sum) abs_sum[ty * ntx + tx] = sum;
+            if (level)
+                for (int i = 0; i < n; i++)
+                    memcpy(level + (size_t)(y0 + i) * cstride + x0, q + i * MAX_CU_SIZE, n * 2);
+            if (rec) {
+                if (sum) {
+                    xDeQuant(t0, q, MAX_CU_SIZE, qp, n, n, (X265_SliceType)st);
+                    xIDctAdd(r, t0, p, MAX_CU_SIZE, t1, t0, n, n, mode);
+                } else {
+                    for (int i = 0; i < n; i++) memcpy(r + i * MAX_CU_SIZE, p + i * MAX_CU_SIZE, n);
+                }
+                for (int i = 0; i < n; i++) memcpy(rec + (size_t)(y0 + i) * rstride + x0, r + i * MAX_CU_SIZE, n);
+            }
+        }
+}
+
+/* Whole intra encoder (BASELINE.json configs[0]): xDefaultParams -> xCheckParams ->
+ * xEncInit -> xEncEncode per frame.  yuv: nframes * w*h*3/2 bytes (Y,U,V planes).
+ * rec_out (same size) receives each frame's reconstruction, bytes_out the
+ * bitstream size per frame, md5_out 16 bytes per frame from the reference's
+ * own MD5 (src/md5.cpp). */
+int ref_encode_intra(const uint8_t *yuv, int w, int h, int cu, int qp, int nframes,
+                     uint8_t *rec_out, int32_t *bytes_out, uint8_t *md5_out, uint8_t *bs_out,
+                     int bs_cap)
+{
+    static X265_t hnd;
+    xDefaultParams(&hnd);
+    hnd.usWidth = (UInt16)w;
+    hnd.usHeight = (UInt16)h;
+    hnd.ucMaxCUWidth = (UInt8)cu;
+    hnd.iQP = qp;
+    hnd.eSliceType = SLICE_I;
+    if (w % cu || h % cu || cu < 16 || w > MAX_WIDTH) return -1; /* xCheckParams would exit() */
+    xCheckParams(&hnd);
+    xEncInit(&hnd);
+    const size_t fsz = (size_t)w * h * 3 / 2;
+    UInt8 *buf = (UInt8 *)malloc(fsz + 65536);
+    int bs_pos = 0;
+    for (int f = 0; f < nframes; f++) {
+        X265_Frame fr;
+        fr.pucY = (UInt8 *)yuv + f * fsz;
+        fr.pucU = fr.pucY + (size_t)w * h;
+        fr.pucV = fr.pucU + (size_t)w * h / 4;
+        Int32 nb = xEncEncode(&hnd, &fr, buf, (UInt32)(fsz + 65536));
+        bytes_out[f] = nb;
+        if (bs_out && bs_pos + nb <= bs_cap) {
+            memcpy(bs_out + bs_pos, buf, nb);
+            bs_pos += nb;
+        }
+        /* after the rotation at src/encode.cpp:965-970 the recon is refn[0] */
+        memcpy(rec_out + f * fsz, hnd.refn[0].pucY, fsz);
+        MD5Context ctx;
+        MD5Init(&ctx);
+        MD5Update(&ctx, hnd.refn[0].pucY, (UInt32)fsz);
+        MD5Final(&ctx, md5_out + 16 * f);
+    }
+    free(buf);
+    xEncFree(&hnd);
+    return bs_pos;
+}
+
+} /* extern "C" */

@@ -1,0 +1,347 @@
+/*
+ * x265_oracle.c -- CPU restatement of the chenm001/x265 ME+TQ hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see x265_oracle.h).  Written fresh from SURVEY.md
+ * App. A: the transforms are stated in table-driven matrix form (the reference
+ * uses partial butterflies, which are an exact integer factorisation of the
+ * same sums), with the reference's Int32 accumulators, arithmetic shifts and
+ * truncating Int16 stores between passes.
+ */
+#include "x265_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------ */
+/* ROM (src/table.cpp:72-171).  The HEVC core transform is generated from    */
+/* its 32 distinct magnitudes (first column of the 32x32 matrix):            */
+/* T32[k][j] = sgn * c[fold(k*(2j+1) mod 128)], T_N[k][j] = T32[k*32/N][j].   */
+/* ------------------------------------------------------------------------ */
+static const int8_t kCos[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+static const int8_t kDst4[16] = {29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29};
+static const int16_t kQuantScale[6] = {26214, 23302, 20560, 18396, 16384, 14564}; /* table.cpp:156 */
+static const uint8_t kInvQuantScale[6] = {40, 45, 51, 57, 64, 72};               /* table.cpp:161 */
+
+static int8_t g_t[4][32 * 32]; /* [log2n-2][k*n+j] */
+static int g_t_ready = 0;
+
+static int t32(int k, int j)
+{
+    int a = (k * (2 * j + 1)) & 127;
+    if (a > 64) a = 128 - a;
+    return a <= 32 ? kCos[a] : -kCos[64 - a];
+}
+
+static void build_tables(void)
+{
+    for (int l = 0; l < 4; l++) {
+        int n = 4 << l;
+        for (int k = 0; k < n; k++)
+            for (int j = 0; j < n; j++) g_t[l][k * n + j] = (int8_t)t32(k * (32 / n), j);
+    }
+    g_t_ready = 1;
+}
+
+static int log2n(int n) /* xLog2(n-1), inc/utils.h:28-36 */
+{
+    int l = 0;
+    unsigned x = (unsigned)(n - 1);
+    while (x) {
+        x >>= 1;
+        l++;
+    }
+    return l;
+}
+
+const int8_t *orc_dct_matrix(int n)
+{
+    if (!g_t_ready) build_tables();
+    return g_t[log2n(n) - 2];
+}
+
+const int8_t *orc_dst4_matrix(void) { return kDst4; }
+
+int orc_chroma_qp(int qp)
+{
+    /* g_aucChromaScale (src/table.cpp:166-171): identity to 29, then the HEVC
+     * draft chroma mapping, saturating at 39. */
+    static const uint8_t tail[22] = {29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36,
+                                     36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+    return qp < 30 ? qp : tail[qp - 30];
+}
+
+static int clip3(int lo, int hi, int a) { return a < lo ? lo : (a > hi ? hi : a); }
+
+/* ------------------------------------------------------------------------ */
+/* SAD: src/pixel.cpp:30-93                                                  */
+/* ------------------------------------------------------------------------ */
+uint32_t orc_sad(int w, int n, const uint8_t *src, int ss, const uint8_t *ref, int sr)
+{
+    uint32_t sad = 0;
+    for (int y = 0; y < n; y++) {
+        const uint8_t *s = src + (size_t)y * ss, *r = ref + (size_t)y * sr;
+        for (int x = 0; x < w; x++) sad += (uint32_t)abs((int)s[x] - (int)r[x]);
+    }
+    return sad;
+}
+
+static uint32_t sad64x64(const uint8_t *src, int ss, const uint8_t *ref, int sr)
+{
+    uint32_t sad = 0;
+    for (int y = 0; y < 64; y++) {
+        const uint8_t *s = src + (size_t)y * ss, *r = ref + (size_t)y * sr;
+        uint32_t row = 0;
+        for (int x = 0; x < 64; x++) row += (uint32_t)abs((int)s[x] - (int)r[x]);
+        sad += row;
+    }
+    return sad;
+}
+
+/* ------------------------------------------------------------------------ */
+/* 1-D transforms: src/pixel.cpp:114-312 (forward), 321-569 (inverse)        */
+/* ------------------------------------------------------------------------ */
+static const int8_t *matrix_for(int idx, int *n)
+{
+    if (idx == 0) {
+        *n = 4;
+        return kDst4;
+    }
+    *n = 2 << idx; /* 1->4 2->8 3->16 4->32 */
+    return orc_dct_matrix(*n);
+}
+
+void orc_fwd_1d(int idx, int16_t *dst, const int16_t *src, unsigned stride, int lines, int shift)
+{
+    int n;
+    const int8_t *m = matrix_for(idx, &n);
+    const int32_t rnd = 1 << (shift - 1);
+    if (idx == 0) lines = 4; /* xDST4 ignores nLines: src/pixel.cpp:138 */
+    for (int i = 0; i < lines; i++)
+        for (int k = 0; k < n; k++) {
+            int32_t acc = 0;
+            for (int j = 0; j < n; j++) acc += (int32_t)m[k * n + j] * (int32_t)src[i * stride + j];
+            dst[k * stride + i] = (int16_t)((acc + rnd) >> shift); /* truncating store */
+        }
+}
+
+void orc_inv_1d(int idx, int16_t *dst, const int16_t *src, unsigned stride, int lines, int shift)
+{
+    int n;
+    const int8_t *m = matrix_for(idx, &n);
+    const int32_t rnd = 1 << (shift - 1);
+    if (idx == 0) lines = 4;  /* xInvDST4 ignores nLines: src/pixel.cpp:351 */
+    if (idx == 4) lines = 32; /* xInvDCT32 ignores nLines: src/pixel.cpp:513 */
+    for (int i = 0; i < lines; i++)
+        for (int j = 0; j < n; j++) {
+            int32_t acc = 0;
+            for (int k = 0; k < n; k++) acc += (int32_t)m[k * n + j] * (int32_t)src[k * stride + i];
+            /* stored to Int16 first, then Clip3 on the stored value => wraps
+             * (src/pixel.cpp:334-342 and SURVEY.md App. C) */
+            int16_t v = (int16_t)((acc + rnd) >> shift);
+            dst[i * stride + j] = (int16_t)clip3(-32768, 32767, v);
+        }
+}
+
+/* ------------------------------------------------------------------------ */
+/* xSubDct: src/pixel.cpp:668-722                                            */
+/* ------------------------------------------------------------------------ */
+void orc_sub_dct(int16_t *dst, const uint8_t *src, const uint8_t *ref, unsigned stride,
+                 int16_t *tmp0, int16_t *tmp1, int w, int h, unsigned mode)
+{
+    const int lw = log2n(w), lh = log2n(h);
+    const int use_dst = (w + h == 8) && (mode != ORC_MODE_INVALID);
+    const int dst_hor = use_dst && (!mode || (mode >= 2 && mode <= 25));  /* :679 */
+    const int dst_ver = use_dst && (!mode || (mode >= 11 && mode <= 34)); /* :680 */
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++)
+            tmp0[i * stride + j] = (int16_t)((int)src[i * stride + j] - (int)ref[i * stride + j]);
+    orc_fwd_1d(lw - 1 - dst_hor, tmp1, tmp0, stride, h, lw - 1); /* :706 */
+    orc_fwd_1d(lh - 1 - dst_ver, dst, tmp1, stride, w, lh + 6);  /* :707 */
+}
+
+/* ------------------------------------------------------------------------ */
+/* xIDctAdd: src/pixel.cpp:724-776                                           */
+/* ------------------------------------------------------------------------ */
+void orc_idct_add(uint8_t *dst, const int16_t *src, const uint8_t *ref, unsigned stride,
+                  int16_t *tmp0, int16_t *tmp1, int w, int h, unsigned mode)
+{
+    const int lw = log2n(w), lh = log2n(h);
+    const int use_dst = (w + h == 8) && (mode != ORC_MODE_INVALID);
+    const int dst_hor = use_dst && (!mode || (mode >= 11 && mode <= 34)); /* :735 (swapped) */
+    const int dst_ver = use_dst && (!mode || (mode >= 2 && mode <= 25));  /* :736 */
+    orc_inv_1d(lw - 1 - dst_hor, tmp0, src, stride, h, 7);   /* SHIFT_INV_1ST */
+    orc_inv_1d(lh - 1 - dst_ver, tmp1, tmp0, stride, w, 12); /* SHIFT_INV_2ND */
+    for (int i = 0; i < h; i++)
+        for (int j = 0; j < w; j++)
+            dst[i * stride + j] =
+                (uint8_t)clip3(0, 255, (int)tmp1[i * stride + j] + (int)ref[i * stride + j]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* xQuant: src/pixel.cpp:591-633                                             */
+/* ------------------------------------------------------------------------ */
+uint32_t orc_quant(int16_t *dst, const int16_t *src, unsigned stride, unsigned qp, int w, int h,
+                   int slice_type)
+{
+    const unsigned q = (unsigned)kQuantScale[qp % 6];
+    const int tshift = 15 - 8 - log2n(w);
+    const int qbits = 14 + (int)(qp / 6) + tshift;
+    const int32_t rnd = (slice_type == ORC_SLICE_I ? 171 : 85) << (qbits - 9);
+    uint32_t sum = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int c = src[y * stride + x];
+            int sign = c < 0 ? -1 : 1;
+            /* unsigned 32-bit multiply-add, logical shift (uiQ is UInt) */
+            int lvl = (int)(((unsigned)abs(c) * q + (unsigned)rnd) >> qbits);
+            sum += (uint32_t)lvl;
+            lvl *= sign;
+            int16_t st = (int16_t)lvl; /* truncating store, then a no-op clip */
+            dst[y * stride + x] = (int16_t)clip3(-32768, 32767, st);
+        }
+    return sum;
+}
+
+/* ------------------------------------------------------------------------ */
+/* xDeQuant: src/pixel.cpp:635-666                                           */
+/* ------------------------------------------------------------------------ */
+void orc_dequant(int16_t *dst, const int16_t *src, unsigned stride, unsigned qp, int w, int h,
+                 int slice_type)
+{
+    (void)slice_type;
+    const int tshift = 15 - 8 - log2n(w);
+    const int shift = 20 - 14 - tshift;
+    const int32_t rnd = 1 << (shift - 1);
+    const int scale = (int)kInvQuantScale[qp % 6] << (qp / 6);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int32_t v = ((int32_t)src[y * stride + x] * scale + rnd) >> shift;
+            dst[y * stride + x] = (int16_t)clip3(-32768, 32767, v);
+        }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Motion search: SURVEY.md App. A.7; argmin idiom src/encode.cpp:725-727,   */
+/* 762-765; MAX_SAD inc/config.h:52.                                         */
+/* ------------------------------------------------------------------------ */
+static void me_one_ctu(const uint8_t *cur, const uint8_t *ref, int width, int height, int stride,
+                       int ctu, int range, int cx, int cy, orc_mv *out)
+{
+    uint32_t best = ORC_MAX_SAD;
+    int bx = 0, by = 0;
+    const uint8_t *c = cur + (size_t)cy * stride + cx;
+    for (int dy = -range; dy <= range; dy++) {
+        int ry = cy + dy;
+        if (ry < 0 || ry + ctu > height) continue;
+        for (int dx = -range; dx <= range; dx++) {
+            int rx = cx + dx;
+            if (rx < 0 || rx + ctu > width) continue;
+            const uint8_t *r = ref + (size_t)ry * stride + rx;
+            uint32_t cost = (ctu == 64) ? sad64x64(c, stride, r, stride)
+                                        : orc_sad(ctu, ctu, c, stride, r, stride);
+            if (cost < best) {
+                best = cost;
+                bx = dx;
+                by = dy;
+            }
+        }
+    }
+    out->mvx = (int16_t)bx;
+    out->mvy = (int16_t)by;
+    out->sad = best;
+}
+
+void orc_me_fullsearch(const uint8_t *cur, const uint8_t *ref, int width, int height, int stride,
+                       int ctu, int range, orc_mv *out, int first_ctu, int step, int count,
+                       int nthreads)
+{
+    const int ncx = width / ctu, ncy = height / ctu, nctu = ncx * ncy;
+    if (step < 1) step = 1;
+    if (count < 0) count = (nctu - first_ctu + step - 1) / step;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+    for (int i = 0; i < count; i++) {
+        int idx = first_ctu + i * step;
+        if (idx >= nctu) continue;
+        me_one_ctu(cur, ref, width, height, stride, ctu, range, (idx % ncx) * ctu,
+                   (idx / ncx) * ctu, &out[idx]);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Frame-level TQ.  Each TU is copied into 32-stride scratch exactly like    */
+/* the reference's per-CU cache (inc/x265.h:105-131) and run through the     */
+/* per-block restatements above.                                             */
+/* ------------------------------------------------------------------------ */
+static void fetch_pred(uint8_t *dst32, const uint8_t *pred, int pstride, const orc_mv *mv,
+                       int mv_ctu, int ncx, int x0, int y0, int n)
+{
+    int ox = 0, oy = 0;
+    if (mv) {
+        const orc_mv *m = &mv[(y0 / mv_ctu) * ncx + (x0 / mv_ctu)];
+        ox = m->mvx;
+        oy = m->mvy;
+    }
+    for (int i = 0; i < n; i++)
+        memcpy(dst32 + i * 32, pred + (size_t)(y0 + oy + i) * pstride + x0 + ox, (size_t)n);
+}
+
+void orc_tq_forward(const uint8_t *src, int sstride, const uint8_t *pred, int pstride,
+                    const orc_mv *mv, int mv_ctu, int width, int height, int n, int qp,
+                    int slice_type, const uint8_t *modes, int16_t *level, int cstride,
+                    uint32_t *abs_sum, int nthreads)
+{
+    const int ntx = width / n, nty = height / n;
+    const int ncx = mv ? width / mv_ctu : 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int ty = 0; ty < nty; ty++) {
+        uint8_t s32[32 * 32], p32[32 * 32];
+        int16_t t0[32 * 32], t1[32 * 32], q[32 * 32];
+        for (int tx = 0; tx < ntx; tx++) {
+            const int x0 = tx * n, y0 = ty * n;
+            for (int i = 0; i < n; i++)
+                memcpy(s32 + i * 32, src + (size_t)(y0 + i) * sstride + x0, (size_t)n);
+            fetch_pred(p32, pred, pstride, mv, mv_ctu, ncx, x0, y0, n);
+            unsigned mode = modes ? modes[ty * ntx + tx] : ORC_MODE_INVALID;
+            orc_sub_dct(t0, s32, p32, 32, t0, t1, n, n, mode); /* in place, encode.cpp:868 */
+            uint32_t s = orc_quant(q, t0, 32, (unsigned)qp, n, n, slice_type);
+            if (abs_sum) abs_sum[ty * ntx + tx] = s;
+            for (int i = 0; i < n; i++)
+                memcpy(level + (size_t)(y0 + i) * cstride + x0, q + i * 32, (size_t)n * 2);
+        }
+    }
+}
+
+void orc_tq_inverse(const int16_t *level, int cstride, const uint8_t *pred, int pstride,
+                    const orc_mv *mv, int mv_ctu, int width, int height, int n, int qp,
+                    int slice_type, const uint8_t *modes, uint8_t *rec, int rstride, int nthreads)
+{
+    const int ntx = width / n, nty = height / n;
+    const int ncx = mv ? width / mv_ctu : 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int ty = 0; ty < nty; ty++) {
+        uint8_t p32[32 * 32], r32[32 * 32];
+        int16_t t0[32 * 32], t1[32 * 32], q[32 * 32];
+        for (int tx = 0; tx < ntx; tx++) {
+            const int x0 = tx * n, y0 = ty * n;
+            uint32_t sum = 0;
+            for (int i = 0; i < n; i++) {
+                memcpy(q + i * 32, level + (size_t)(y0 + i) * cstride + x0, (size_t)n * 2);
+                for (int j = 0; j < n; j++) sum += (uint32_t)abs((int)q[i * 32 + j]);
+            }
+            fetch_pred(p32, pred, pstride, mv, mv_ctu, ncx, x0, y0, n);
+            unsigned mode = modes ? modes[ty * ntx + tx] : ORC_MODE_INVALID;
+            if (sum) { /* encode.cpp:893-900 */
+                orc_dequant(t0, q, 32, (unsigned)qp, n, n, slice_type);
+                orc_idct_add(r32, t0, p32, 32, t1, t0, n, n, mode);
+            } else { /* encode.cpp:901-905 */
+                for (int i = 0; i < n; i++) memcpy(r32 + i * 32, p32 + i * 32, (size_t)n);
+            }
+            for (int i = 0; i < n; i++)
+                memcpy(rec + (size_t)(y0 + i) * rstride + x0, r32 + i * 32, (size_t)n);
+        }
+    }
+}
