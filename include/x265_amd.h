@@ -1,0 +1,194 @@
+/*
+ * x265_amd.h -- C-ABI of the MI355X (gfx950) ME + transform/quant hot path.
+ *
+ * This is the drop-in boundary for the data-parallel path of chenm001/x265:
+ * the three plug-in tables and four free functions of the reference's pixel
+ * layer (inc/x265.h:290-298), re-cut from "one block per call" into "one
+ * picture plane (or a batch of planes) per call", because a GPU launch per
+ * 32x32 block would be all overhead.  Every entry point below names the
+ * reference interface it replaces (paths are under /root/reference).
+ *
+ * Conventions
+ *  - plain C types only; every pointer marked `d_` is DEVICE memory (HBM).
+ *  - every function returns int: 0 = ok, negative = error (x265amd_strerror()).
+ *    Nothing aborts or exits (the reference asserts / exit()s instead:
+ *    src/params.cpp:80-83, src/pixel.cpp:684).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *    Calls are asynchronous on that stream; nothing here allocates or
+ *    synchronises except x265amd_malloc, _free, _memcpy_h2d, _memcpy_d2h and _stream_sync.
+ *  - picture planes are 8-bit, row-major, stride in bytes (the reference keeps
+ *    stride == width: src/encode.cpp:41-45; here any stride works).  Widths and
+ *    heights must be multiples of the block size in use, exactly like
+ *    src/params.cpp:73-74 demands of the CU size.
+ *  - coefficient planes are Int16 in PICTURE GEOMETRY: level[y][x] belongs to
+ *    the pixel position (x, y); the TU that owns it is (x / tu, y / tu).
+ *  - a library instance is bound to one device per host thread (x265amd_init);
+ *    different devices are independent (one process or thread per GPU).
+ */
+#ifndef X265_AMD_H
+#define X265_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X265AMD_VERSION 100
+
+/* eIntraMode MODE_INVALID, inc/x265.h:70: "no intra mode" => always DCT */
+#define X265AMD_MODE_INVALID 255
+
+/* X265_SliceType, inc/x265.h:39-43 (selects the quantiser rounding offset) */
+#define X265AMD_SLICE_I 0
+#define X265AMD_SLICE_P 1
+#define X265AMD_SLICE_B 2
+
+/* MAX_SAD, inc/config.h:52 */
+#define X265AMD_MAX_SAD (1u << 30)
+
+enum {
+    X265AMD_OK = 0,
+    X265AMD_ERR_ARG = -1,       /* bad geometry / null pointer / unsupported size */
+    X265AMD_ERR_NO_DEVICE = -2, /* no HIP device, or device index out of range */
+    X265AMD_ERR_ARCH = -3,      /* device is not gfx950 */
+    X265AMD_ERR_NOT_INIT = -4,  /* x265amd_init() not called */
+    X265AMD_ERR_LDS = -5,       /* search window does not fit the 160 KiB LDS */
+    X265AMD_ERR_HIP = -1000     /* -1000 - hipError_t */
+};
+
+/* One motion vector + its cost, 8 bytes.  (The reference has no MV type:
+ * P slices are `assert(0)` at src/encode.cpp:581-584.) */
+typedef struct x265amd_mv {
+    int16_t mvx, mvy; /* integer-pel displacement of the best candidate */
+    uint32_t sad;     /* its SAD (what xSadN[] would return) */
+} x265amd_mv;
+
+/* ---------------------------------------------------------------- runtime */
+
+/* Select `device`, check it is gfx950, load the kernels.  Replaces nothing in
+ * the reference (it has no device); closest relative is xEncInit,
+ * src/encode.cpp:33-52.  Idempotent. */
+int x265amd_init(int device);
+int x265amd_version(void);
+const char *x265amd_strerror(int status);
+
+/* Device memory + copies so that a C/C++ host needs no HIP headers
+ * (xEncInit's MALLOC of the frame buffers, src/encode.cpp:40-46; xEncFree :54-62). */
+int x265amd_malloc(void **d_ptr, size_t bytes);
+int x265amd_free(void *d_ptr);
+int x265amd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
+int x265amd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+int x265amd_stream_sync(void *stream);
+
+/* g_aucChromaScale[qp], src/table.cpp:166-171 (QP used for the chroma planes,
+ * src/encode.cpp:596).  Host-side helper, no device work.  qp 0..51. */
+int x265amd_chroma_qp(int qp);
+
+/* -------------------------------------------------------------------- SAD */
+
+/* Batched xSadN[log2(w)-2](n, src, stride_src, ref, stride_ref)
+ * (typedef xSad + table: inc/x265.h:290-291, src/pixel.cpp:30-101).
+ * Block b compares the w x n block at d_src + src_off[b] with the one at
+ * d_ref + ref_off[b]; out[b] receives the UInt32 the reference returns.
+ * w in {4,8,16,32,64}, 1 <= n <= 64. */
+int x265amd_sad_blocks(int w, int n, const uint8_t *d_src, int stride_src, const uint8_t *d_ref,
+                       int stride_ref, const uint32_t *d_src_off, const uint32_t *d_ref_off,
+                       int nblocks, uint32_t *d_out, void *stream);
+
+/* ---------------------------------------------------------- motion search */
+
+/* Exhaustive integer-pel search, one vector per ctu x ctu block (SURVEY.md
+ * App. A.7).  The reference has no search of its own; this is the loop its
+ * encode.cpp would run over xSadN[log2(ctu)-2] (src/pixel.cpp:30-41) with its
+ * argmin idiom (`best = MAX_SAD; if (cost < best)`, src/encode.cpp:725-727,
+ * 762-765): candidates (dx, dy) in [-range, range]^2 in raster order, dy
+ * outer; candidates whose block leaves the picture are skipped; the first
+ * strict minimum wins.
+ *
+ * Batched over frames and references:
+ *   cur(f)    = d_cur + f * cur_frame_stride
+ *   ref(f, r) = d_ref + f * ref_frame_stride + r * ref_ref_stride   (strides in bytes, may be negative)
+ *   d_out[(f * nrefs + r) * nctu + cty * (width / ctu) + ctx]
+ * ctu in {16, 32, 64}; width, height multiples of ctu; stride a multiple of 4
+ * and planes 4-byte aligned; (ctu + 2*range + 8)^2 + ctu^2 bytes must fit in LDS
+ * (range <= 128 at ctu 64). */
+int x265amd_me_fullsearch(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
+                          int stride, int ctu, int range, int nframes, int64_t cur_frame_stride,
+                          int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride,
+                          x265amd_mv *d_out, void *stream);
+
+/* -------------------------------------------------------- transform/quant */
+
+/* One descriptor for the three TQ entry points.  Planes are batched over
+ * `nframes`; plane(f) = base + f * <name>_frame_stride (in ELEMENTS of that
+ * plane's type).  Unused pointers may be NULL. */
+typedef struct x265amd_tq_desc {
+    int32_t width, height; /* plane size in pixels; multiples of `tu` */
+    int32_t tu;            /* transform size: 4, 8, 16 or 32 (CU = PU = TU like src/encode.cpp:486-489) */
+    int32_t qp;            /* 0..51; pass x265amd_chroma_qp(qp) for chroma planes */
+    int32_t slice_type;    /* X265AMD_SLICE_*: rounding 171 (I) or 85 (P/B), src/pixel.cpp:602 */
+    int32_t nframes;
+
+    const uint8_t *d_src; /* original picture (forward, roundtrip) */
+    int32_t src_stride;
+    int64_t src_frame_stride;
+
+    /* prediction.  With d_mv == NULL: a plane in picture geometry (intra
+     * prediction output / co-located block).  With d_mv != NULL: the REFERENCE
+     * picture; the prediction of pixel (x, y) is ref[y + mvy][x + mvx] with the
+     * vector of the mv_ctu x mv_ctu block containing (x, y) -- integer-pel motion
+     * compensation fused into the load. */
+    const uint8_t *d_pred;
+    int32_t pred_stride;
+    int64_t pred_frame_stride;
+    const x265amd_mv *d_mv;
+    int32_t mv_ctu;
+    int64_t mv_frame_stride;
+
+    /* per-TU intra mode (nMode of xSubDct/xIDctAdd; selects DST for 4x4:
+     * src/pixel.cpp:678-680,734-736); NULL = X265AMD_MODE_INVALID everywhere */
+    const uint8_t *d_modes;
+    int64_t modes_frame_stride;
+
+    int16_t *d_level; /* quantised levels: OUT of forward/roundtrip, IN of inverse */
+    int32_t level_stride;
+    int64_t level_frame_stride;
+
+    int16_t *d_coef; /* optional OUT of forward: unquantised xSubDct output, same layout as level */
+
+    uint32_t *d_abs_sum; /* optional OUT: xQuant's return value per TU, [ (height/tu) * (width/tu) ] */
+    int64_t abs_sum_frame_stride;
+
+    uint8_t *d_rec; /* reconstruction: OUT of inverse/roundtrip */
+    int32_t rec_stride;
+    int64_t rec_frame_stride;
+} x265amd_tq_desc;
+
+/* xSubDct + xQuant for every TU of the plane(s)
+ * (inc/x265.h:295,297; src/pixel.cpp:668-722,591-633; call site src/encode.cpp:868-873). */
+int x265amd_tq_forward(const x265amd_tq_desc *desc, void *stream);
+
+/* xDeQuant + xIDctAdd for every TU (inc/x265.h:296,298; src/pixel.cpp:635-666,
+ * 724-776; call site src/encode.cpp:893-925; a TU whose levels are all zero
+ * reconstructs to the prediction exactly as the memcpy branch there does). */
+int x265amd_tq_inverse(const x265amd_tq_desc *desc, void *stream);
+
+/* forward + inverse in one pass over the picture (the whole "Stage 3a/3b" of
+ * src/encode.cpp:863-925): writes level, abs_sum and rec without the
+ * coefficient round trip through HBM. */
+int x265amd_tq_roundtrip(const x265amd_tq_desc *desc, void *stream);
+
+/* Stand-alone quantiser stages on a coefficient plane, for stage-by-stage
+ * checking in the manner of the reference's CHECK_TV blocks
+ * (xQuant src/pixel.cpp:591-633, xDeQuant :635-666).  In and out may alias. */
+int x265amd_quant_plane(const int16_t *d_coef, int16_t *d_level, int stride, int width, int height,
+                        int tu, int qp, int slice_type, uint32_t *d_abs_sum, void *stream);
+int x265amd_dequant_plane(const int16_t *d_level, int16_t *d_coef, int stride, int width,
+                          int height, int tu, int qp, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265_AMD_H */

@@ -1,0 +1,12 @@
+"""x265_amd -- MI355X (gfx950) native ME + transform/quant hot path of chenm001/x265.
+
+The product is lib/libx265amd.so (hand-written HIP kernels behind the C-ABI of
+include/x265_amd.h).  This package is its Python host side: ctypes bindings that
+take torch CUDA tensors (torch = device memory + streams only), the synthetic
+sequence generator, and the frame-sharding helper for multi-GPU runs.
+"""
+from .api import (LIB_PATH, MAX_SAD, MODE_INVALID, MV_DTYPE, SLICE_B, SLICE_I, SLICE_P, X265AmdError,  # noqa: F401
+                  chroma_qp, dequant_plane, init, load_library, me_fullsearch, mv_to_numpy, quant_plane,
+                  sad_blocks, tq_forward, tq_inverse, tq_roundtrip)
+
+__version__ = "0.1.0"

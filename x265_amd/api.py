@@ -1,0 +1,298 @@
+"""ctypes binding of include/x265_amd.h plus a thin host layer that mirrors the
+reference's pixel-layer interface (inc/x265.h:290-298) at picture granularity.
+
+PyTorch is used for device memory and streams only.  There is no CPU path here:
+if lib/libx265amd.so is missing or the device is not gfx950, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libx265amd.so")
+
+MODE_INVALID = 255            # inc/x265.h:70
+SLICE_I, SLICE_P, SLICE_B = 0, 1, 2   # inc/x265.h:39-43
+MAX_SAD = 1 << 30             # inc/config.h:52
+
+MV_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("sad", "<u4")])
+
+
+class X265AmdError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = _lib().x265amd_strerror(status).decode() if _LIB is not None else "library not loaded"
+        super().__init__(f"{where}: {msg} (status {status})")
+
+
+class TqDesc(C.Structure):
+    """x265amd_tq_desc, include/x265_amd.h"""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("tu", C.c_int32), ("qp", C.c_int32),
+        ("slice_type", C.c_int32), ("nframes", C.c_int32),
+        ("d_src", C.c_void_p), ("src_stride", C.c_int32), ("src_frame_stride", C.c_int64),
+        ("d_pred", C.c_void_p), ("pred_stride", C.c_int32), ("pred_frame_stride", C.c_int64),
+        ("d_mv", C.c_void_p), ("mv_ctu", C.c_int32), ("mv_frame_stride", C.c_int64),
+        ("d_modes", C.c_void_p), ("modes_frame_stride", C.c_int64),
+        ("d_level", C.c_void_p), ("level_stride", C.c_int32), ("level_frame_stride", C.c_int64),
+        ("d_coef", C.c_void_p),
+        ("d_abs_sum", C.c_void_p), ("abs_sum_frame_stride", C.c_int64),
+        ("d_rec", C.c_void_p), ("rec_stride", C.c_int32), ("rec_frame_stride", C.c_int64),
+    ]
+
+
+_LIB = None
+
+# name -> (restype, argtypes); every symbol include/x265_amd.h declares
+SIGNATURES = {
+    "x265amd_init": (C.c_int, [C.c_int]),
+    "x265amd_version": (C.c_int, []),
+    "x265amd_strerror": (C.c_char_p, [C.c_int]),
+    "x265amd_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "x265amd_free": (C.c_int, [C.c_void_p]),
+    "x265amd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "x265amd_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "x265amd_stream_sync": (C.c_int, [C.c_void_p]),
+    "x265amd_chroma_qp": (C.c_int, [C.c_int]),
+    "x265amd_sad_blocks": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "x265amd_me_fullsearch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                         C.c_void_p]),
+    "x265amd_tq_forward": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
+    "x265amd_tq_inverse": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
+    "x265amd_tq_roundtrip": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
+    "x265amd_quant_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, C.c_void_p, C.c_void_p]),
+    "x265amd_dequant_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p]),
+}
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: build it with `make -C x265_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = lib
+    return _LIB
+
+
+def load_library():
+    """Load lib/libx265amd.so and bind every declared symbol (no GPU needed)."""
+    return _lib()
+
+
+def _check(status, where):
+    if status != 0:
+        raise X265AmdError(status, where)
+
+
+def init(device=0):
+    """x265amd_init: bind this process to `device` (must be gfx950)."""
+    _check(_lib().x265amd_init(int(device)), "x265amd_init")
+    torch.cuda.set_device(device)
+
+
+def chroma_qp(qp):
+    r = _lib().x265amd_chroma_qp(int(qp))
+    if r < 0:
+        raise X265AmdError(r, "x265amd_chroma_qp")
+    return r
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, dtype, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype):
+        raise TypeError(f"{name}: expected a CUDA tensor of {dtype}, got {type(t)} {getattr(t, 'dtype', None)}")
+    return t
+
+
+def _planes(t, dtype, name):
+    """[H][W] or [F][H][W] tensor with unit pixel stride -> (ptr, nframes, H, W, row stride, frame stride)."""
+    _dev(t, dtype, name)
+    if t.dim() == 2:
+        t = t.unsqueeze(0)
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError(f"{name}: need [F][H][W] with contiguous rows")
+    f, h, w = t.shape
+    return t.data_ptr(), f, h, w, t.stride(1), (t.stride(0) if f > 1 else 0)
+
+
+# --------------------------------------------------------------------------
+# xSadN[] (inc/x265.h:290-291)
+# --------------------------------------------------------------------------
+def sad_blocks(w, n, src, stride_src, ref, stride_ref, src_off, ref_off):
+    """Batched xSadN[log2(w)-2](n, src+src_off[b], stride_src, ref+ref_off[b], stride_ref)."""
+    _dev(src, torch.uint8, "src"), _dev(ref, torch.uint8, "ref")
+    _dev(src_off, torch.int32, "src_off"), _dev(ref_off, torch.int32, "ref_off")
+    nb = src_off.numel()
+    if ref_off.numel() != nb:
+        raise ValueError("src_off / ref_off length mismatch")
+    out = torch.empty(nb, dtype=torch.int32, device=src.device)
+    _check(_lib().x265amd_sad_blocks(w, n, src.data_ptr(), stride_src, ref.data_ptr(), stride_ref,
+                                     src_off.data_ptr(), ref_off.data_ptr(), nb, out.data_ptr(), _stream()),
+           "x265amd_sad_blocks")
+    return out
+
+
+# --------------------------------------------------------------------------
+# motion search
+# --------------------------------------------------------------------------
+def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None):
+    """cur: uint8 [F][H][W]; ref: uint8 [F][H][W] (one reference per frame) or
+    [F][R][H][W] (R references per frame).  Returns int32 [F][R][nctu][2] viewed as
+    (mvx|mvy<<16, sad) -- use mv_to_numpy() for a structured host copy."""
+    cp, f, h, w, cs, cfs = _planes(cur, torch.uint8, "cur")
+    _dev(ref, torch.uint8, "ref")
+    if ref.dim() == 2:
+        ref = ref.unsqueeze(0)
+    if ref.dim() == 3:
+        ref = ref.unsqueeze(1)
+    if ref.dim() != 4 or ref.shape[0] != f or ref.shape[2:] != (h, w) or ref.stride(3) != 1 or ref.stride(2) != cs:
+        raise ValueError("ref: need [F][R][H][W] with the row stride of cur")
+    nrefs = ref.shape[1]
+    nctu = (h // ctu) * (w // ctu) if ctu > 0 else 0
+    if out is None:
+        out = torch.empty((f, nrefs, max(nctu, 0), 2), dtype=torch.int32, device=cur.device)
+    _check(_lib().x265amd_me_fullsearch(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs,
+                                        ref.stride(0) if f > 1 else 0, nrefs, ref.stride(1) if nrefs > 1 else 0,
+                                        out.data_ptr(), _stream()), "x265amd_me_fullsearch")
+    return out
+
+
+def mv_to_numpy(mv):
+    """int32 [...][2] device tensor -> structured numpy array (mvx, mvy, sad)."""
+    a = mv.detach().cpu().numpy()
+    return np.ascontiguousarray(a).view(MV_DTYPE).reshape(a.shape[:-1])
+
+
+# --------------------------------------------------------------------------
+# xSubDct + xQuant / xDeQuant + xIDctAdd (inc/x265.h:295-298)
+# --------------------------------------------------------------------------
+def _tq_desc(tu, qp, slice_type, src=None, pred=None, mv=None, mv_ctu=64, modes=None, level=None, coef=None,
+             abs_sum=None, rec=None, pred_origin=(0, 0)):
+    d = TqDesc()
+    geom = None
+    if src is not None:
+        d.d_src, f, h, w, d.src_stride, d.src_frame_stride = _planes(src, torch.uint8, "src")
+        geom = (f, h, w)
+    if level is not None:
+        d.d_level, f, h, w, d.level_stride, d.level_frame_stride = _planes(level, torch.int16, "level")
+        if geom is not None and geom != (f, h, w):
+            raise ValueError("level / src geometry mismatch")
+        geom = (f, h, w)
+    if geom is None:
+        raise ValueError("need src or level")
+    f, h, w = geom
+    d.width, d.height, d.tu, d.qp, d.slice_type, d.nframes = w, h, tu, qp, slice_type, f
+    pp, pf, ph, pw, d.pred_stride, d.pred_frame_stride = _planes(pred, torch.uint8, "pred")
+    if pf != f:
+        raise ValueError("pred / src frame count mismatch")
+    oy, ox = pred_origin
+    if mv is None and (ph - oy < h or pw - ox < w):
+        raise ValueError("pred plane smaller than the picture")
+    d.d_pred = pp + oy * d.pred_stride + ox
+    if mv is not None:
+        _dev(mv, torch.int32, "mv")
+        nctu = (h // mv_ctu) * (w // mv_ctu)
+        if mv.numel() != f * nctu * 2 or not mv.is_contiguous():
+            raise ValueError("mv: need contiguous int32 [F][nctu][2]")
+        d.d_mv, d.mv_ctu, d.mv_frame_stride = mv.data_ptr(), mv_ctu, nctu
+    if modes is not None:
+        _dev(modes, torch.uint8, "modes")
+        ntu = (h // tu) * (w // tu)
+        if modes.numel() != f * ntu or not modes.is_contiguous():
+            raise ValueError("modes: need contiguous uint8 [F][ntu]")
+        d.d_modes, d.modes_frame_stride = modes.data_ptr(), ntu
+    if coef is not None:
+        cp, cf, chh, cw, cstr, cfs = _planes(coef, torch.int16, "coef")
+        if (cf, chh, cw, cstr, cfs) != (f, h, w, d.level_stride, d.level_frame_stride):
+            raise ValueError("coef must have the layout of level")
+        d.d_coef = cp
+    if abs_sum is not None:
+        _dev(abs_sum, torch.int32, "abs_sum")
+        d.d_abs_sum, d.abs_sum_frame_stride = abs_sum.data_ptr(), (h // tu) * (w // tu)
+    if rec is not None:
+        d.d_rec, rf, rh, rw, d.rec_stride, d.rec_frame_stride = _planes(rec, torch.uint8, "rec")
+        if (rf, rh, rw) != (f, h, w):
+            raise ValueError("rec / picture geometry mismatch")
+    return d
+
+
+def _alloc_like(src, dtype, tu=None):
+    s = src if src.dim() == 3 else src.unsqueeze(0)
+    f, h, w = s.shape
+    if tu is None:
+        return torch.empty((f, h, w), dtype=dtype, device=src.device)
+    return torch.empty((f, (h // tu) * (w // tu)), dtype=dtype, device=src.device)
+
+
+def tq_forward(src, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, want_coef=False,
+               pred_origin=(0, 0)):
+    """xSubDct + xQuant over whole planes.  Returns (level, abs_sum[, coef])."""
+    level = _alloc_like(src, torch.int16)
+    sums = _alloc_like(src, torch.int32, tu if tu in (4, 8, 16, 32) else 4)
+    coef = _alloc_like(src, torch.int16) if want_coef else None
+    d = _tq_desc(tu, qp, slice_type, src=src, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level,
+                 coef=coef, abs_sum=sums, pred_origin=pred_origin)
+    _check(_lib().x265amd_tq_forward(C.byref(d), _stream()), "x265amd_tq_forward")
+    return (level, sums, coef) if want_coef else (level, sums)
+
+
+def tq_inverse(level, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, pred_origin=(0, 0)):
+    """xDeQuant + xIDctAdd over whole planes.  Returns rec."""
+    rec = _alloc_like(level, torch.uint8)
+    d = _tq_desc(tu, qp, slice_type, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level, rec=rec,
+                 pred_origin=pred_origin)
+    _check(_lib().x265amd_tq_inverse(C.byref(d), _stream()), "x265amd_tq_inverse")
+    return rec
+
+
+def tq_roundtrip(src, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, pred_origin=(0, 0),
+                 out=None):
+    """Fused forward + inverse (src/encode.cpp:863-925).  Returns (level, abs_sum, rec).
+    `out` = (level, abs_sum, rec) preallocated tensors to reuse (no allocation in the call)."""
+    if out is None:
+        level = _alloc_like(src, torch.int16)
+        sums = _alloc_like(src, torch.int32, tu if tu in (4, 8, 16, 32) else 4)
+        rec = _alloc_like(src, torch.uint8)
+    else:
+        level, sums, rec = out
+    d = _tq_desc(tu, qp, slice_type, src=src, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level,
+                 abs_sum=sums, rec=rec, pred_origin=pred_origin)
+    _check(_lib().x265amd_tq_roundtrip(C.byref(d), _stream()), "x265amd_tq_roundtrip")
+    return level, sums, rec
+
+
+def quant_plane(coef, tu, qp, slice_type=SLICE_I):
+    """xQuant on a coefficient plane [H][W] -> (level, abs_sum)."""
+    _dev(coef, torch.int16, "coef")
+    h, w = coef.shape
+    level = torch.empty_like(coef)
+    sums = torch.empty(((h // tu) * (w // tu)) if tu > 0 else 0, dtype=torch.int32, device=coef.device)
+    _check(_lib().x265amd_quant_plane(coef.data_ptr(), level.data_ptr(), coef.stride(0), w, h, tu, qp, slice_type,
+                                      sums.data_ptr(), _stream()), "x265amd_quant_plane")
+    return level, sums
+
+
+def dequant_plane(level, tu, qp):
+    """xDeQuant on a level plane [H][W] -> coef."""
+    _dev(level, torch.int16, "level")
+    h, w = level.shape
+    coef = torch.empty_like(level)
+    _check(_lib().x265amd_dequant_plane(level.data_ptr(), coef.data_ptr(), level.stride(0), w, h, tu, qp, _stream()),
+           "x265amd_dequant_plane")
+    return coef

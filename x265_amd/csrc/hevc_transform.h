@@ -1,0 +1,132 @@
+// hevc_transform.h -- compile-time HEVC core-transform ROM and exact integer
+// partial butterflies for gfx950 device code.
+//
+// The ROM (reference: g_aiT4/8/16/32, src/table.cpp:72-145) is never stored: it
+// is generated at compile time from the 32 distinct magnitudes of the 32-point
+// matrix, and every coefficient ends up as an instruction literal.  The
+// butterflies are the recursive even/odd factorisation the reference unrolls by
+// hand (src/pixel.cpp:114-312 forward, 321-569 inverse); all sums are Int32, so
+// they equal the reference's sums bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+
+namespace x265amd {
+
+// |T32[a][0]| for a = 0..32 (cosine magnitudes, 64 * sqrt(2) * cos(a*pi/64) rounded by the standard)
+template <int A> struct CosMag;
+#define X265AMD_COS(a, v) \
+    template <> struct CosMag<a> { static constexpr int value = v; };
+X265AMD_COS(0, 64) X265AMD_COS(1, 90) X265AMD_COS(2, 90) X265AMD_COS(3, 90) X265AMD_COS(4, 89)
+X265AMD_COS(5, 88) X265AMD_COS(6, 87) X265AMD_COS(7, 85) X265AMD_COS(8, 83) X265AMD_COS(9, 82)
+X265AMD_COS(10, 80) X265AMD_COS(11, 78) X265AMD_COS(12, 75) X265AMD_COS(13, 73) X265AMD_COS(14, 70)
+X265AMD_COS(15, 67) X265AMD_COS(16, 64) X265AMD_COS(17, 61) X265AMD_COS(18, 57) X265AMD_COS(19, 54)
+X265AMD_COS(20, 50) X265AMD_COS(21, 46) X265AMD_COS(22, 43) X265AMD_COS(23, 38) X265AMD_COS(24, 36)
+X265AMD_COS(25, 31) X265AMD_COS(26, 25) X265AMD_COS(27, 22) X265AMD_COS(28, 18) X265AMD_COS(29, 13)
+X265AMD_COS(30, 9) X265AMD_COS(31, 4) X265AMD_COS(32, 0)
+#undef X265AMD_COS
+
+// T_N[K][J] = T32[K * 32 / N][J]; T32[k][j] = sgn * mag[fold(k * (2j + 1) mod 128)]
+template <int N, int K, int J> struct Coef {
+    static constexpr int a0 = ((K * (32 / N)) * (2 * J + 1)) & 127;
+    static constexpr int a1 = a0 > 64 ? 128 - a0 : a0;
+    static constexpr int value = a1 <= 32 ? CosMag<(a1 <= 32 ? a1 : 0)>::value
+                                          : -CosMag<(a1 > 32 ? 64 - a1 : 0)>::value;
+};
+
+// 24-bit multiply is full rate on the VALU (v_mul_i32_i24 / v_mad_i32_i24); every
+// operand here is at most 18 bits (Int16 data after <= 2 butterfly add levels,
+// 8-bit coefficients), so it is exact.
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+
+// sum_{j < M} T_N[R][j] * v[j]
+template <int N, int R, int... J>
+__device__ __forceinline__ int dot_row(const int *v, std::integer_sequence<int, J...>)
+{
+    return (mul24(Coef<N, R, J>::value, v[J]) + ...);
+}
+// sum_{k < M} T_N[2k+1][C] * v[2k+1]   (odd rows, column C)
+template <int N, int C, int... K>
+__device__ __forceinline__ int dot_col_odd(const int *v, std::integer_sequence<int, K...>)
+{
+    return (mul24(Coef<N, 2 * K + 1, C>::value, v[2 * K + 1]) + ...);
+}
+
+template <int N, int... K>
+__device__ __forceinline__ void fwd_odd(const int *o, int *y, std::integer_sequence<int, K...>)
+{
+    ((y[2 * K + 1] = dot_row<N, 2 * K + 1>(o, std::make_integer_sequence<int, N / 2>{})), ...);
+}
+template <int N, int... C>
+__device__ __forceinline__ void inv_odd(const int *y, int *o, std::integer_sequence<int, C...>)
+{
+    ((o[C] = dot_col_odd<N, C>(y, std::make_integer_sequence<int, N / 2>{})), ...);
+}
+
+// y[k] = sum_j T_N[k][j] x[j]   (xDCT4/8/16/32 without the rounding shift)
+template <int N> __device__ __forceinline__ void fwd_butterfly(const int *x, int *y)
+{
+    if constexpr (N == 2) {
+        y[0] = (x[0] + x[1]) * 64;
+        y[1] = (x[0] - x[1]) * 64;
+    } else {
+        int e[N / 2], o[N / 2], ye[N / 2];
+#pragma unroll
+        for (int k = 0; k < N / 2; k++) {
+            e[k] = x[k] + x[N - 1 - k];
+            o[k] = x[k] - x[N - 1 - k];
+        }
+        fwd_butterfly<N / 2>(e, ye);
+#pragma unroll
+        for (int k = 0; k < N / 2; k++) y[2 * k] = ye[k];
+        fwd_odd<N>(o, y, std::make_integer_sequence<int, N / 2>{});
+    }
+}
+
+// x[j] = sum_k T_N[k][j] y[k]   (xInvDCT4/8/16/32 without the rounding shift)
+template <int N> __device__ __forceinline__ void inv_butterfly(const int *y, int *x)
+{
+    if constexpr (N == 2) {
+        x[0] = (y[0] + y[1]) * 64;
+        x[1] = (y[0] - y[1]) * 64;
+    } else {
+        int ye[N / 2], e[N / 2], o[N / 2];
+#pragma unroll
+        for (int k = 0; k < N / 2; k++) ye[k] = y[2 * k];
+        inv_butterfly<N / 2>(ye, e);
+        inv_odd<N>(y, o, std::make_integer_sequence<int, N / 2>{});
+#pragma unroll
+        for (int j = 0; j < N / 2; j++) {
+            x[j] = e[j] + o[j];
+            x[N - 1 - j] = e[j] - o[j];
+        }
+    }
+}
+
+// 4-point DST-VII (xDST4 src/pixel.cpp:133-151; xInvDST4 :346-369), matrix
+// {29,55,74,84; 74,74,0,-74; 84,-29,-74,55; 55,-84,74,-29}
+__device__ __forceinline__ void fwd_dst4(const int *x, int *y)
+{
+    y[0] = mul24(29, x[0]) + mul24(55, x[1]) + mul24(74, x[2]) + mul24(84, x[3]);
+    y[1] = mul24(74, x[0] + x[1] - x[3]);
+    y[2] = mul24(84, x[0]) - mul24(29, x[1]) - mul24(74, x[2]) + mul24(55, x[3]);
+    y[3] = mul24(55, x[0]) - mul24(84, x[1]) + mul24(74, x[2]) - mul24(29, x[3]);
+}
+__device__ __forceinline__ void inv_dst4(const int *y, int *x)
+{
+    x[0] = mul24(29, y[0]) + mul24(74, y[1]) + mul24(84, y[2]) + mul24(55, y[3]);
+    x[1] = mul24(55, y[0]) + mul24(74, y[1]) - mul24(29, y[2]) - mul24(84, y[3]);
+    x[2] = mul24(74, y[0] - y[2] + y[3]);
+    x[3] = mul24(84, y[0]) - mul24(74, y[1]) + mul24(55, y[2]) - mul24(29, y[3]);
+}
+
+// DST selection by intra mode (src/pixel.cpp:678-680).  `hor` = the pass over x.
+__device__ __forceinline__ bool use_dst(int n, unsigned mode, bool hor)
+{
+    if (n != 4 || mode == 255u) return false;
+    if (mode == 0) return true;
+    return hor ? (mode >= 2 && mode <= 25) : (mode >= 11 && mode <= 34);
+}
+
+}  // namespace x265amd

@@ -1,0 +1,89 @@
+// runtime.hip -- device selection, error strings, memory helpers of the C-ABI
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace x265amd {
+
+static std::mutex g_mu;
+static bool g_init = false;
+static int g_lds_limit = 64 * 1024;
+
+bool initialised() { return g_init; }
+int lds_limit_bytes() { return g_lds_limit; }
+
+}  // namespace x265amd
+
+using namespace x265amd;
+
+extern "C" int x265amd_version(void) { return X265AMD_VERSION; }
+
+extern "C" int x265amd_init(int device)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return X265AMD_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return X265AMD_ERR_NO_DEVICE;
+    X265AMD_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    X265AMD_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return X265AMD_ERR_ARCH;  // kernels are built for gfx950 only
+    int lds = 0;
+    if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
+        g_lds_limit = lds;
+    g_init = true;
+    return X265AMD_OK;
+}
+
+extern "C" const char *x265amd_strerror(int status)
+{
+    switch (status) {
+    case X265AMD_OK: return "ok";
+    case X265AMD_ERR_ARG: return "invalid argument (geometry, size, alignment or null pointer)";
+    case X265AMD_ERR_NO_DEVICE: return "no such HIP device";
+    case X265AMD_ERR_ARCH: return "device is not gfx950 (MI355X); this library has no other code path";
+    case X265AMD_ERR_NOT_INIT: return "x265amd_init() has not been called";
+    case X265AMD_ERR_LDS: return "search window does not fit in LDS";
+    default: break;
+    }
+    if (status <= X265AMD_ERR_HIP) return hipGetErrorString((hipError_t)(X265AMD_ERR_HIP - status));
+    return "unknown status";
+}
+
+extern "C" int x265amd_malloc(void **d_ptr, size_t bytes)
+{
+    if (!d_ptr) return X265AMD_ERR_ARG;
+    X265AMD_HIP(hipMalloc(d_ptr, bytes));
+    return X265AMD_OK;
+}
+extern "C" int x265amd_free(void *d_ptr)
+{
+    X265AMD_HIP(hipFree(d_ptr));
+    return X265AMD_OK;
+}
+extern "C" int x265amd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+    X265AMD_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return X265AMD_OK;
+}
+extern "C" int x265amd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    X265AMD_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return X265AMD_OK;
+}
+extern "C" int x265amd_stream_sync(void *stream)
+{
+    X265AMD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return X265AMD_OK;
+}
+
+extern "C" int x265amd_chroma_qp(int qp)
+{
+    // g_aucChromaScale (src/table.cpp:166-171): identity below 30, then the draft's chroma mapping
+    static const unsigned char tail[22] = {29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36,
+                                           36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+    if (qp < 0 || qp > 51) return X265AMD_ERR_ARG;
+    return qp < 30 ? qp : tail[qp - 30];
+}
