@@ -17,7 +17,7 @@
 typedef short short2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
 
-constexpr int ITERS = 4096;
+constexpr int ITERS = 32768;
 constexpr int CHAINS = 8;
 
 // each kernel: CHAINS independent dependency chains of one instruction, ITERS iterations
@@ -26,12 +26,18 @@ constexpr int CHAINS = 8;
     {                                                                              \
         uint32_t t = threadIdx.x + blockIdx.x * 256u + seed;                       \
         decl;                                                                      \
+        const uint64_t c0 = clock64(), w0 = wall_clock64();                        \
         for (int it = 0; it < ITERS; it++) {                                       \
             _Pragma("unroll") for (int c = 0; c < CHAINS; c++) { body; }           \
         }                                                                          \
         uint32_t r = 0;                                                            \
         _Pragma("unroll") for (int c = 0; c < CHAINS; c++) { fold; }               \
+        const uint64_t c1 = clock64(), w1 = wall_clock64();                        \
         if (r == 0x12345678u) out[t & 1023] = r;                                   \
+        if (blockIdx.x == 7 && threadIdx.x == 0) {                                 \
+            ((uint64_t *)out)[600] = c1 - c0;                                      \
+            ((uint64_t *)out)[601] = w1 - w0;                                      \
+        }                                                                          \
     }
 
 KERNEL(k_add_u32, uint32_t a[CHAINS]; for (int c = 0; c < CHAINS; c++) a[c] = t + c,
@@ -95,7 +101,7 @@ int main(int argc, char **argv)
     printf("device: %s  CUs=%d  clock=%d kHz  LDS/block=%zu\n", prop.gcnArchName, prop.multiProcessorCount,
            prop.clockRate, prop.sharedMemPerBlock);
     uint32_t *out;
-    CHECK(hipMalloc(&out, 4096));
+    CHECK(hipMalloc(&out, 8192));
     Entry tab[] = {
         {"v_add_u32", k_add_u32, 1, "op"},          {"v_sad_u8", k_sad_u8, 4, "px"},
         {"v_sad_u8(sgpr)", k_sad_u8_sgpr, 4, "px"},  {"v_msad_u8", k_msad_u8, 4, "px"},
@@ -114,7 +120,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
-    printf("%-20s %10s %14s %16s %12s\n", "instruction", "ms", "Tlane-op/s", "cyc/wave-instr", "T<unit>/s");
+    printf("%-20s %10s %14s %16s %12s %14s %10s\n", "instruction", "ms", "Tlane-op/s", "cyc@2.4GHz", "T<unit>/s", "shader-cyc/wi", "GHz");
     for (auto &e : tab) {
         hipLaunchKernelGGL(e.fn, dim3(blocks), dim3(256), 0, 0, out, 1u);  // warm-up
         CHECK(hipDeviceSynchronize());
@@ -131,7 +137,13 @@ int main(int argc, char **argv)
         // cycles one SIMD spends per wave-instruction, assuming 2.4 GHz and all SIMDs busy
         const double wave_instr_per_simd = (double)waves_per_simd * ITERS * CHAINS;
         const double cyc = ms * 1e-3 * 2.4e9 / wave_instr_per_simd;
-        printf("%-20s %10.3f %14.3f %16.2f %9.2f %s\n", e.name, ms, rate * 1e-12, cyc, rate * e.work * 1e-12, e.unit);
+        uint64_t tm[2];
+        CHECK(hipMemcpy(tm, (uint64_t *)out + 600, 16, hipMemcpyDeviceToHost));
+        // in-kernel: shader cycles one SIMD spends per wave-instruction, and the shader clock (s_memrealtime = 100 MHz)
+        const double scyc = (double)tm[0] / wave_instr_per_simd;
+        const double ghz = (double)tm[0] / ((double)tm[1] * 10.0);
+        printf("%-20s %10.3f %14.3f %16.2f %9.2f %-3s %14.2f %10.3f\n", e.name, ms, rate * 1e-12, cyc, rate * e.work * 1e-12,
+               e.unit, scyc, ghz);
     }
     CHECK(hipFree(out));
     return 0;
