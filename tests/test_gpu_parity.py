@@ -263,8 +263,9 @@ def test_me_argument_errors(gpu):
         gpu.me_fullsearch(a, a, 48, 16)         # CTU size not supported
     with pytest.raises(gpu.X265AmdError):
         gpu.me_fullsearch(a[:100], a[:100], 64, 16)  # height not a multiple of the CTU
+    big = torch.zeros((1024, 1024), dtype=torch.uint8, device="cuda")
     with pytest.raises(gpu.X265AmdError):
-        gpu.me_fullsearch(a, a, 64, 300)        # window cannot fit LDS
+        gpu.me_fullsearch(big, big, 64, 300)    # (64 + 600)^2 window cannot fit the 160 KiB LDS
 
 
 def test_me_then_tq_pipeline_vs_oracle(gpu, oracle):
