@@ -1,0 +1,58 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol
+include/x265_amd.h declares; argument errors come back as status codes, never aborts."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "x265_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(x265amd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_path():
+    syms = declared_symbols()
+    for need in ("x265amd_init", "x265amd_sad_blocks", "x265amd_me_fullsearch", "x265amd_tq_forward",
+                 "x265amd_tq_inverse", "x265amd_tq_roundtrip", "x265amd_quant_plane", "x265amd_dequant_plane",
+                 "x265amd_strerror"):
+        assert need in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from x265_amd import api
+    assert os.path.exists(api.LIB_PATH), "build first: make -C x265_amd/csrc (or __graft_entry__.build())"
+    lib = C.CDLL(api.LIB_PATH)
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/x265_amd.h but not exported"
+    assert sorted(api.SIGNATURES) == declared_symbols(), "python binding table out of sync with the header"
+
+
+def test_host_side_helpers_without_gpu():
+    from x265_amd import api
+    lib = api.load_library()
+    assert lib.x265amd_version() == 100
+    # g_aucChromaScale, src/table.cpp:166-171
+    want = list(range(30)) + [29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39]
+    assert [api.chroma_qp(q) for q in range(52)] == want
+    with pytest.raises(api.X265AmdError):
+        api.chroma_qp(52)
+    assert b"argument" in lib.x265amd_strerror(-1)
+    assert b"gfx950" in lib.x265amd_strerror(-3)
+
+
+def test_desc_struct_layout_matches_header():
+    """sizeof / field order of the ctypes mirror of x265amd_tq_desc (natural C alignment)."""
+    from x265_amd import api
+    names = [f[0] for f in api.TqDesc._fields_]
+    text = open(os.path.join(ROOT, "include", "x265_amd.h")).read()
+    body = text[text.index("typedef struct x265amd_tq_desc {"):text.index("} x265amd_tq_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    decl = re.findall(r"\b(?:const\s+)?[a-z0-9_]+(?:\s*\*)?\s*\**\s*([a-z_0-9]+(?:\s*,\s*[a-z_0-9]+)*)\s*;", body)
+    flat = [n.strip() for d in decl for n in d.split(",")]
+    assert flat == names
+    assert C.sizeof(api.TqDesc) == 184   # sizeof(x265amd_tq_desc) from gcc
