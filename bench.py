@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--me-method", default="sea", choices=["sea", "brute"],
+                    help="sea: exact successive elimination (default); brute: every candidate's SAD. Same output.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -132,7 +134,7 @@ def main():
     frames_np = make_frames(nw, nh, ctu, rng, fps + nrefs, seed=12345 + 1000 * rank)
     h, w = frames_np.shape[1:]
     frames = torch.from_numpy(frames_np).cuda()
-    pipe = MeTqPipeline(frames, ctu=ctu, search_range=rng, nrefs=nrefs, tu=tu, qp=qp)
+    pipe = MeTqPipeline(frames, ctu=ctu, search_range=rng, nrefs=nrefs, tu=tu, qp=qp, method=args.me_method)
     nctu = pipe.nctu
 
     def barrier():
@@ -199,8 +201,8 @@ def main():
             "config": {"workload": f"{nw}x{nh} 8-bit luma (padded {w}x{h}), {ctu}x{ctu} CTU, +-{rng} integer-pel "
                                    f"full search, {nrefs} ref(s), then {tu}x{tu} DCT+quant+recon QP{qp}; "
                                    f"{fps} frames per step per GPU, frames sharded across GPUs, no collective",
-                       "name": args.workload, "frames_per_step_per_gpu": fps},
-            "roofline": {"kernel": "me_fullsearch", "bound": "hbm", "achieved": round(achieved, 3),
+                       "name": args.workload, "frames_per_step_per_gpu": fps, "me_method": pipe.method},
+            "roofline": {"kernel": "me_sea_kernel (+ box16_h/v)" if pipe.method == "sea" else "me_fullsearch_qsad", "bound": "hbm", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "algorithmic_bytes_per_launch": me_bytes,
                          "avg_launch_ms": round(me_ms, 4),

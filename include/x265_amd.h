@@ -119,6 +119,20 @@ int x265amd_me_fullsearch(const uint8_t *d_cur, const uint8_t *d_ref, int width,
                           int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride,
                           x265amd_mv *d_out, void *stream);
 
+/* The same search with EXACT successive elimination: identical vectors and
+ * costs (ties included), far fewer SADs.  A candidate is dropped only when a
+ * lower bound of its SAD (sum over the sixteen 16x16 sub-blocks of
+ * |sum(cur) - sum(ref)|) exceeds the SAD of a candidate already evaluated, so
+ * the first strict minimum of src/encode.cpp:762-765 is untouched.  Needs a
+ * caller-provided device workspace of x265amd_me_workspace_bytes() bytes
+ * (16-byte aligned) for the reference box sums; ctu must be 64. */
+size_t x265amd_me_workspace_bytes(int width, int height, int nframes, int nrefs);
+int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
+                              int stride, int ctu, int range, int nframes,
+                              int64_t cur_frame_stride, int64_t ref_frame_stride, int nrefs,
+                              int64_t ref_ref_stride, x265amd_mv *d_out, void *d_workspace,
+                              size_t workspace_bytes, void *stream);
+
 /* -------------------------------------------------------- transform/quant */
 
 /* One descriptor for the three TQ entry points.  Planes are batched over

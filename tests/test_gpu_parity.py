@@ -173,57 +173,67 @@ def test_tq_argument_errors(gpu):
 
 
 # ---------------------------------------------------------------- ME ------
-def test_me_golden(gpu):
+@pytest.mark.parametrize("method", ["brute", "sea"])
+def test_me_golden(gpu, method):
     z, meta = load_golden("me_small.npz")
     for m in meta:
         k = m["id"]
-        got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(z[f"me{k}_cur"]), dev(z[f"me{k}_ref"]), m["ctu"], m["range"]))
+        if method == "sea" and m["ctu"] != 64:
+            continue
+        got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(z[f"me{k}_cur"]), dev(z[f"me{k}_ref"]), m["ctu"], m["range"],
+                                                method=method))
         want = z[f"me{k}_mv"]
         for f in ("mvx", "mvy", "sad"):
             np.testing.assert_array_equal(got[0, 0][f], want[f], f"{f} {m}")
 
 
+@pytest.mark.parametrize("method", ["brute", "sea"])
 @pytest.mark.parametrize("ctu,rng_,w,h", [(64, 64, 256, 192), (64, 33, 320, 128), (32, 24, 160, 96),
                                           (16, 16, 96, 64), (64, 128, 192, 192), (64, 1, 128, 64),
                                           (64, 0, 128, 64)])
-def test_me_vs_oracle(gpu, oracle, ctu, rng_, w, h):
+def test_me_vs_oracle(gpu, oracle, ctu, rng_, w, h, method):
     from x265_amd import synth
+    if method == "sea" and ctu != 64:
+        pytest.skip("successive elimination is built for the 64x64 CTU only")
     seq = synth.make_sequence(w, h, 3, search_range=min(rng_, 48), seed=ctu * 1000 + rng_)
     cur = np.ascontiguousarray(seq[1:])
     ref = np.ascontiguousarray(seq[:-1])
-    got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, rng_))
+    got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, rng_, method=method))
     for f in range(2):
         want = oracle.me_fullsearch(cur[f], ref[f], ctu, rng_, nthreads=8)
         np.testing.assert_array_equal(got[f, 0], want, f"frame {f}")
 
 
-def test_me_ties_pick_first_in_raster_order(gpu, oracle):
+@pytest.mark.parametrize("method", ["brute", "sea"])
+def test_me_ties_pick_first_in_raster_order(gpu, oracle, method):
     """Periodic content => many exact ties; the winner must be the first candidate in
     (dy outer, dx inner) order -- the reference's strict `<` (src/encode.cpp:762)."""
     w, h = 256, 128
     yy, xx = np.mgrid[0:h, 0:w]
     img = (((xx % 8) * 16 + (yy % 4) * 3) & 255).astype(np.uint8)
-    got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(img), dev(img.copy()), 64, 20))[0, 0]
+    got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(img), dev(img.copy()), 64, 20, method=method))[0, 0]
     want = oracle.me_fullsearch(img, img.copy(), 64, 20, nthreads=8)
     np.testing.assert_array_equal(got, want)
     assert (want["sad"] == 0).all() and (want["mvy"] <= 0).all()
 
 
-def test_me_multi_reference(gpu, oracle):
+@pytest.mark.parametrize("method", ["brute", "sea"])
+def test_me_multi_reference(gpu, oracle, method):
     """BASELINE.json configs[4] shape at small size: 4 reference frames per current frame."""
     from x265_amd import synth
     seq = synth.make_sequence(192, 128, 6, search_range=16, seed=31)
     f, nref = 2, 4
     cur = np.ascontiguousarray(seq[4:6])
     refs = np.stack([np.stack([seq[4 + i - 1 - r] for r in range(nref)]) for i in range(f)])
-    got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(refs), 64, 24))
+    got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(refs), 64, 24, method=method))
     for i in range(f):
         for r in range(nref):
             want = oracle.me_fullsearch(cur[i], np.ascontiguousarray(refs[i, r]), 64, 24, nthreads=8)
             np.testing.assert_array_equal(got[i, r], want, f"frame {i} ref {r}")
 
 
-def test_me_1080p_properties(gpu, oracle):
+@pytest.mark.parametrize("method", ["brute", "sea"])
+def test_me_1080p_properties(gpu, oracle, method):
     """BASELINE.json configs[1] at full size (1920x1088, CTU 64, R 64).  The CPU oracle needs
     ~0.1 s per CTU, so: (a) exact comparison on every 17th CTU, (b) for ALL CTUs the
     returned cost is the true SAD at the returned vector (recomputed by the independent
@@ -232,7 +242,7 @@ def test_me_1080p_properties(gpu, oracle):
     W, H, R = 1920, 1088, 64
     seq = synth.make_sequence(W, H, 2, search_range=R, seed=12345)
     cur, ref = dev(seq[1]), dev(seq[0])
-    mv = gpu.mv_to_numpy(gpu.me_fullsearch(cur, ref, 64, R))[0, 0]
+    mv = gpu.mv_to_numpy(gpu.me_fullsearch(cur, ref, 64, R, method=method))[0, 0]
     ncx = W // 64
     nctu = mv.size
     want = oracle.me_fullsearch(seq[1], seq[0], 64, R, first=3, step=17, count=-1, nthreads=16)
@@ -255,6 +265,27 @@ def test_me_1080p_properties(gpu, oracle):
         ro = dev(((cy + dy) * W + cx + dx).astype(np.int32))
         s = host(gpu.sad_blocks(64, 64, cur.view(-1), W, ref.view(-1), W, so, ro)).astype(np.uint32)
         assert (mv["sad"] <= s).all()
+
+
+def test_me_sea_equals_exhaustive_on_hostile_content(gpu):
+    """Successive elimination must return exactly what the exhaustive kernel returns whatever
+    the content: white noise (bounds useless), flat (everything ties), a 1080p frame pair with
+    unrelated content (no good match anywhere), and real motion."""
+    from x265_amd import synth
+    rng = np.random.default_rng(11)
+    cases = []
+    cases.append((rng.integers(0, 256, (192, 256), dtype=np.uint8), rng.integers(0, 256, (192, 256), dtype=np.uint8), 40))
+    flat = np.full((128, 192), 77, np.uint8)
+    cases.append((flat, flat.copy(), 33))
+    a = synth.make_sequence(1920, 1088, 1, seed=1)[0]
+    b = synth.make_sequence(1920, 1088, 1, seed=2)[0]
+    cases.append((a, np.ascontiguousarray(b[::-1]), 64))
+    seq = synth.make_sequence(640, 384, 2, search_range=64, seed=5)
+    cases.append((seq[1], seq[0], 64))
+    for cur, ref, r in cases:
+        x = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), 64, r, method="brute"))
+        y = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), 64, r, method="sea"))
+        np.testing.assert_array_equal(x, y)
 
 
 def test_me_argument_errors(gpu):

@@ -61,6 +61,10 @@ SIGNATURES = {
     "x265amd_me_fullsearch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
+    "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "x265amd_tq_forward": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
     "x265amd_tq_inverse": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
     "x265amd_tq_roundtrip": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
@@ -151,10 +155,19 @@ def sad_blocks(w, n, src, stride_src, ref, stride_ref, src_off, ref_off):
 # --------------------------------------------------------------------------
 # motion search
 # --------------------------------------------------------------------------
-def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None):
+def me_workspace_bytes(width, height, nframes, nrefs):
+    return int(_lib().x265amd_me_workspace_bytes(width, height, nframes, nrefs))
+
+
+def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", workspace=None):
     """cur: uint8 [F][H][W]; ref: uint8 [F][H][W] (one reference per frame) or
     [F][R][H][W] (R references per frame).  Returns int32 [F][R][nctu][2] viewed as
-    (mvx|mvy<<16, sad) -- use mv_to_numpy() for a structured host copy."""
+    (mvx|mvy<<16, sad) -- use mv_to_numpy() for a structured host copy.
+
+    method: "brute" = x265amd_me_fullsearch (every candidate's SAD), "sea" =
+    x265amd_me_fullsearch_sea (exact successive elimination, same result; CTU 64 only;
+    `workspace` = uint8 CUDA tensor of me_workspace_bytes() or None to allocate one),
+    "auto" = "sea" where it applies."""
     cp, f, h, w, cs, cfs = _planes(cur, torch.uint8, "cur")
     _dev(ref, torch.uint8, "ref")
     if ref.dim() == 2:
@@ -167,9 +180,26 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None):
     nctu = (h // ctu) * (w // ctu) if ctu > 0 else 0
     if out is None:
         out = torch.empty((f, nrefs, max(nctu, 0), 2), dtype=torch.int32, device=cur.device)
-    _check(_lib().x265amd_me_fullsearch(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs,
-                                        ref.stride(0) if f > 1 else 0, nrefs, ref.stride(1) if nrefs > 1 else 0,
-                                        out.data_ptr(), _stream()), "x265amd_me_fullsearch")
+    if method not in ("auto", "brute", "sea"):
+        raise ValueError("method")
+    use_sea = method == "sea" or (method == "auto" and ctu == 64 and w > 0 and h > 0 and w % 64 == 0 and h % 64 == 0)
+    if use_sea:
+        need = me_workspace_bytes(w, h, f, nrefs)
+        if workspace is None:
+            workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=cur.device)
+        _dev(workspace, torch.uint8, "workspace")
+        st = _lib().x265amd_me_fullsearch_sea(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs,
+                                              ref.stride(0) if f > 1 else 0, nrefs,
+                                              ref.stride(1) if nrefs > 1 else 0, out.data_ptr(),
+                                              workspace.data_ptr(), workspace.numel(), _stream())
+        if st == -5 and method == "auto":   # X265AMD_ERR_LDS: bounds + window do not fit; exhaustive kernel does
+            use_sea = False
+        else:
+            _check(st, "x265amd_me_fullsearch_sea")
+    if not use_sea:
+        _check(_lib().x265amd_me_fullsearch(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs,
+                                            ref.stride(0) if f > 1 else 0, nrefs, ref.stride(1) if nrefs > 1 else 0,
+                                            out.data_ptr(), _stream()), "x265amd_me_fullsearch")
     return out
 
 

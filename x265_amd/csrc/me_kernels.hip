@@ -5,6 +5,7 @@
 // defined by SURVEY.md App. A.7 with the reference's argmin idiom
 // (src/encode.cpp:725-727,762-765).
 #include "common.h"
+#include "me_common.h"
 
 namespace x265amd {
 
@@ -155,27 +156,6 @@ __global__ __launch_bounds__(256) void me_fullsearch_basic(const MeParams p)
 // partial sums are widened to u32 every 4 rows (64 * 1020 < 65536).
 // Winner = min over (sad << 32 | raster index) by wave shuffles.
 // ---------------------------------------------------------------------------
-struct MeGeom {
-    int width, height, stride, range, nrefs, ctus_x, ctus_y;
-    int64_t cur_fs, ref_fs, ref_rs;
-};
-
-constexpr int kMeT = 3;  // dy rows per lane: 129 = 43 * 3 and 257 = 86 * 3 - 1 leave (almost) no waste
-
-__host__ __device__ inline void me_qsad_layout(int w, int h, int range, int cx, int cy, int &dylo, int &dyhi, int &dxlo,
-                                               int &dxhi, int &wx0, int &ngx, int &ngy, int &pitch, int &win_rows)
-{
-    dylo = -range > -cy ? -range : -cy;
-    dyhi = range < h - 64 - cy ? range : h - 64 - cy;
-    dxlo = -range > -cx ? -range : -cx;
-    dxhi = range < w - 64 - cx ? range : w - 64 - cx;
-    wx0 = (cx + dxlo) & ~3;                       // window origin on a dword boundary
-    ngx = (cx + dxlo - wx0 + (dxhi - dxlo + 1) + 3) >> 2;  // groups of 4 consecutive dx
-    ngy = (dyhi - dylo + 1 + kMeT - 1) / kMeT;
-    pitch = (ngx + 17) | 1;                       // dwords; odd => rows spread over the banks
-    win_rows = 64 + kMeT * ngy;
-}
-
 __global__ __launch_bounds__(256, 2) void me_fullsearch_qsad(const uint8_t *__restrict__ cur_base,
                                                              const uint8_t *__restrict__ ref_base,
                                                              x265amd_mv *__restrict__ out, const MeGeom g)

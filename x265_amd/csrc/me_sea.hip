@@ -1,0 +1,493 @@
+// me_sea.hip -- exhaustive integer-pel search with EXACT successive elimination.
+//
+// Same result as x265amd_me_fullsearch (identical vectors and costs, ties
+// included), fewer SADs.  For a candidate c the sum over the sixteen 16x16
+// sub-blocks b of |sum_b(cur) - sum_b(ref at c)| is a lower bound LB(c) <= SAD(c)
+// (triangle inequality).  A candidate whose bound exceeds the SAD of ANY
+// candidate already evaluated cannot be the strict minimum, and cannot tie it
+// either, so dropping it changes nothing: if the true winner c* were dropped we
+// would have LB(c*) > best >= SAD(c*) >= LB(c*).  Everything with LB <= best is
+// evaluated exactly with v_qsad_pk_u16_u8, and the winner is the minimum of the
+// 64-bit key (sad << 32 | raster index) over what was evaluated -- the
+// reference's "first strict minimum" (src/encode.cpp:762-765).
+//
+// Three kernels:
+//   box16_h / box16_v : B16[y][x] = sum of the 16x16 reference block at (x, y), u16
+//                       (16*16*255 < 2^16), separable, coalesced, HBM-bound;
+//   me_sea_kernel     : per (CTU, ref, frame) workgroup -- window to LDS, bounds for
+//                       every legal candidate (v_sad_u32 against the CTU's own
+//                       sub-block sums), histogram pick of a first batch, exact
+//                       SADs, then everything whose bound is still <= best.
+#include "common.h"
+#include "me_common.h"
+
+namespace x265amd {
+
+// ------------------------------------------------------------------ box sums
+// horizontal: H16[y][x] = sum_{k<16} p[y][x+k]; a thread makes 4 consecutive x from 5 aligned dwords
+__global__ __launch_bounds__(256) void box16_h(const uint8_t *__restrict__ ref_base, uint16_t *__restrict__ hbuf,
+                                               int width, int height, int stride, int nrefs, int64_t ref_fs,
+                                               int64_t ref_rs)
+{
+    const int xq = blockIdx.x * 256 + threadIdx.x;  // group of 4 pixels
+    const int y = blockIdx.y;
+    const int pl = blockIdx.z;
+    const int f = pl / nrefs, r = pl - f * nrefs;
+    if (4 * xq >= width) return;
+    const uint8_t *row = ref_base + f * ref_fs + r * ref_rs + (int64_t)y * stride;
+    uint32_t d[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) d[i] = (4 * (xq + i) + 4 <= width) ? *reinterpret_cast<const uint32_t *>(row + 4 * (xq + i)) : 0u;
+    uint32_t s0 = __builtin_amdgcn_sad_u8(d[0], 0u, 0u);
+    s0 = __builtin_amdgcn_sad_u8(d[1], 0u, s0);
+    s0 = __builtin_amdgcn_sad_u8(d[2], 0u, s0);
+    s0 = __builtin_amdgcn_sad_u8(d[3], 0u, s0);
+    const uint32_t s1 = s0 - (d[0] & 255u) + (d[4] & 255u);
+    const uint32_t s2 = s1 - ((d[0] >> 8) & 255u) + ((d[4] >> 8) & 255u);
+    const uint32_t s3 = s2 - ((d[0] >> 16) & 255u) + ((d[4] >> 16) & 255u);
+    uint2 o;
+    o.x = s0 | (s1 << 16);
+    o.y = s2 | (s3 << 16);
+    *reinterpret_cast<uint2 *>(hbuf + ((int64_t)pl * height + y) * width + 4 * xq) = o;
+}
+
+// vertical: B16[y][x] = sum_{k<16} H16[y+k][x]; a thread owns 2 columns (packed u16) and a run of rows
+constexpr int kBoxVRows = 32;
+__global__ __launch_bounds__(256) void box16_v(const uint16_t *__restrict__ hbuf, uint16_t *__restrict__ bbuf, int width,
+                                               int height)
+{
+    const int xp = blockIdx.x * 256 + threadIdx.x;  // pair of columns
+    const int y0 = blockIdx.y * kBoxVRows;
+    const int pl = blockIdx.z;
+    if (2 * xp >= width) return;
+    const uint32_t *h = reinterpret_cast<const uint32_t *>(hbuf + (int64_t)pl * height * width) + xp;
+    uint32_t *b = reinterpret_cast<uint32_t *>(bbuf + (int64_t)pl * height * width) + xp;
+    const int wp = width >> 1;
+    if (y0 + 16 > height) return;
+    uint32_t acc = 0;  // two u16 sums; 16 * 4080 < 2^16, so the packed add never carries across
+#pragma unroll
+    for (int k = 0; k < 16; k++) acc += h[(int64_t)(y0 + k) * wp];
+    b[(int64_t)y0 * wp] = acc;
+    for (int y = y0 + 1; y < y0 + kBoxVRows && y + 16 <= height; y++) {
+        // packed u16 pair: take the old row out first (each half contains it: no borrow), then the
+        // new row in (each half <= 16 * 4080 < 2^16: no carry)
+        acc = (acc - h[(int64_t)(y - 1) * wp]) + h[(int64_t)(y + 15) * wp];
+        b[(int64_t)y * wp] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ search
+struct SeaLayout {
+    int dylo, dyhi, dxlo, dxhi, wx0, ngx, ndy, pitch, win_rows;
+    int ngroups;
+};
+
+__host__ __device__ inline SeaLayout sea_layout(int w, int h, int range, int cx, int cy)
+{
+    SeaLayout L;
+    L.dylo = -range > -cy ? -range : -cy;
+    L.dyhi = range < h - 64 - cy ? range : h - 64 - cy;
+    L.dxlo = -range > -cx ? -range : -cx;
+    L.dxhi = range < w - 64 - cx ? range : w - 64 - cx;
+    L.wx0 = (cx + L.dxlo) & ~3;
+    L.ngx = (cx + L.dxlo - L.wx0 + (L.dxhi - L.dxlo + 1) + 3) >> 2;
+    L.ndy = L.dyhi - L.dylo + 1;
+    L.pitch = (L.ngx + 17) | 1;
+    L.win_rows = 64 + L.ndy;
+    L.ngroups = L.ngx * L.ndy;
+    return L;
+}
+
+constexpr int kBins = 96;         // quarter-octave bins of the bound: covers 24 octaves
+constexpr uint32_t kDone = 0x80000000u;
+
+__device__ __forceinline__ int lb_bin(uint32_t lb)
+{
+    if (lb < 4) return (int)lb;
+    const int msb = 31 - __clz((int)lb);
+    return 4 * (msb - 1) + (int)((lb >> (msb - 2)) & 3u);  // lb=4 -> 4, monotone, < 96 for lb < 2^24
+}
+
+constexpr int kSeaThreads = 512;  // 8 waves; two workgroups per CU => 4 waves per SIMD hide the bound loads
+
+__global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *__restrict__ cur_base,
+                                                                const uint8_t *__restrict__ ref_base,
+                                                                const uint16_t *__restrict__ bbuf,
+                                                                x265amd_mv *__restrict__ out, const MeGeom g,
+                                                                int max_groups, int win_dwords,
+                                                                uint32_t *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *win = smem;                       // [win_rows][pitch] reference window
+    uint32_t *glb = smem + win_dwords;          // [ndy][ngx] bound of each 4-candidate group (min over its legal members)
+    uint16_t *list = reinterpret_cast<uint16_t *>(glb + max_groups);  // groups scheduled for exact evaluation
+    __shared__ __attribute__((aligned(16))) uint32_t part[8 * 64 * 4];  // partial SADs: [wave][lane][4 dx]
+    __shared__ uint32_t hist[kBins];
+    __shared__ uint32_t csum[16];               // the CTU's own sixteen 16x16 sums
+    __shared__ unsigned long long best_key;
+    __shared__ int list_n, pick_bin;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: keeps the current rows in SGPRs
+    const int ctx = blockIdx.x, cty = blockIdx.y;
+    const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
+    const int cx = ctx * 64, cy = cty * 64;
+    const int R = g.range;
+    const SeaLayout L = sea_layout(g.width, g.height, R, cx, cy);
+    const uint8_t *cur = cur_base + f * g.cur_fs;
+    const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
+    const uint16_t *B = bbuf + (int64_t)blockIdx.z * g.height * g.width;
+    const int span = 2 * R + 1;
+
+    long long tmark = stats ? clock64() : 0;
+    uint32_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SEA_MARK(i)                                     \
+    if (stats) {                                        \
+        const long long now_ = clock64();               \
+        st_[i] += (uint32_t)(now_ - tmark);             \
+        tmark = now_;                                   \
+    }
+    // ---- stage the reference window (exact SADs need it): a wave per row, a lane per dword,
+    //      four rows in flight ----
+    for (int qb = 0; qb < L.pitch; qb += 64) {
+        const int wq = qb + lane;
+        const int gx = L.wx0 + 4 * wq;
+        const bool colok = wq < L.pitch;
+        const bool inpic = colok && gx + 4 <= g.width;
+        for (int row0 = wave; row0 < L.win_rows; row0 += 32) {
+            uint32_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = row0 + 8 * j, gy = cy + L.dylo + row;
+                v[j] = 0;  // outside the picture: only ever paired with candidates that are masked below
+                if (inpic && row < L.win_rows && gy < g.height)
+                    v[j] = *reinterpret_cast<const uint32_t *>(ref + (int64_t)gy * g.stride + gx);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int row = row0 + 8 * j;
+                if (colok && row < L.win_rows) win[row * L.pitch + wq] = v[j];
+            }
+        }
+    }
+    if (tid < kBins) hist[tid] = 0;
+    if (tid == 0) {
+        best_key = ~0ull;
+        list_n = 0;
+    }
+    // ---- the CTU's sub-block sums: 16 lanes per sub-block, one 16-pixel row each ----
+    if (tid < 256) {
+        const int b = tid >> 4, rrow = tid & 15;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(cur + (int64_t)(cy + 16 * (b >> 2) + rrow) * g.stride + cx + 16 * (b & 3));
+        uint32_t s = __builtin_amdgcn_sad_u8(p[0], 0u, 0u);
+        s = __builtin_amdgcn_sad_u8(p[1], 0u, s);
+        s = __builtin_amdgcn_sad_u8(p[2], 0u, s);
+        s = __builtin_amdgcn_sad_u8(p[3], 0u, s);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+        if (rrow == 0) csum[b] = s;
+    }
+    __syncthreads();
+    SEA_MARK(3)
+    uint32_t cs[16];
+#pragma unroll
+    for (int b = 0; b < 16; b++) cs[b] = __builtin_amdgcn_readfirstlane(csum[b]);
+
+    // ---- bounds.  Group = 4 window-aligned dx at one dy.  The bound of the group at row dyi needs the
+    //      box sums of rows dyi, dyi+16, dyi+32, dyi+48 -- and so do its neighbours 16 rows up and
+    //      down.  A lane therefore walks a CHAIN dyi = c, c+16, c+32, .. at fixed gx and keeps the four
+    //      row bands in registers: 4 eight-byte loads per group instead of 16 (coalesced along gx). ----
+    const int a = cx + L.dxlo - L.wx0;  // window column of dxlo
+    const int ndx = L.dxhi - L.dxlo + 1;
+    {
+        const int nchain = 16 * L.ngx;  // (c, gx)
+        for (int t = tid; t < nchain; t += kSeaThreads) {
+            const int c = t / L.ngx, gx = t - c * L.ngx;
+            if (c >= L.ndy) continue;
+            const uint16_t *bp = B + (int64_t)(cy + L.dylo + c) * g.width + L.wx0 + 4 * gx;
+            const int64_t band = (int64_t)16 * g.width;
+            uint32_t legal = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int dxi = 4 * gx + q - a;
+                if (dxi >= 0 && dxi < ndx) legal |= 1u << q;
+            }
+            uint2 bnd[4][4];  // [band j][k]
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) bnd[j + 1][k] = *reinterpret_cast<const uint2 *>(bp + j * band + 16 * k);
+            for (int dyi = c, m = 0; dyi < L.ndy; dyi += 16, m++) {
+#pragma unroll
+                for (int j = 0; j < 3; j++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) bnd[j][k] = bnd[j + 1][k];
+#pragma unroll
+                for (int k = 0; k < 4; k++) bnd[3][k] = *reinterpret_cast<const uint2 *>(bp + (m + 3) * band + 16 * k);
+                uint32_t lb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint2 v = bnd[j][k];
+                        const uint32_t sc = cs[4 * j + k];
+                        const uint32_t v0 = v.x & 0xffffu, v1 = v.x >> 16, v2 = v.y & 0xffffu, v3 = v.y >> 16;
+                        lb[0] += v0 > sc ? v0 - sc : sc - v0;  // v_sad_u32
+                        lb[1] += v1 > sc ? v1 - sc : sc - v1;
+                        lb[2] += v2 > sc ? v2 - sc : sc - v2;
+                        lb[3] += v3 > sc ? v3 - sc : sc - v3;
+                    }
+                uint32_t mn = 0xffffffffu;
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (legal & (1u << q)) mn = min(mn, lb[q]);
+                glb[dyi * L.ngx + gx] = mn;
+                if (mn != 0xffffffffu) atomicAdd(&hist[lb_bin(mn)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    SEA_MARK(4)
+
+    // ---- first batch: the lowest bins until at least 256 groups ----
+    if (tid < 64) {
+        uint32_t c0 = hist[tid], c1 = (tid + 64 < kBins) ? hist[tid + 64] : 0u;
+        uint32_t s0 = c0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(s0, o);
+            if (lane >= o) s0 += t;
+        }
+        const uint32_t tot0 = __shfl(s0, 63);
+        uint32_t s1 = c1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(s1, o);
+            if (lane >= o) s1 += t;
+        }
+        s1 += tot0;
+        const unsigned long long m0 = __ballot(s0 >= 256u), m1 = __ballot(s1 >= 256u && tid + 64 < kBins);
+        if (tid == 0) pick_bin = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : kBins);
+    }
+    __syncthreads();
+
+    const uint32_t *__restrict__ cbase = reinterpret_cast<const uint32_t *>(cur + (int64_t)cy * g.stride + cx);
+    const int cstr = g.stride >> 2;
+    const int set = wave >> 2, qtr = wave & 3;  // exact phase: 2 sets of 64 groups x 4 row quarters
+
+    for (int pass = 0; pass < 2; pass++) {
+        // ---- schedule: pass 0 = the picked bins; pass 1 = everything not yet done whose bound <= best ----
+        const uint32_t best_sad = (uint32_t)(best_key >> 32);
+        const int pb = pick_bin;
+        __syncthreads();
+        if (tid == 0) list_n = 0;
+        __syncthreads();
+        for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
+            const int gi = g0 + tid;
+            const uint32_t v = gi < L.ngroups ? glb[gi] : kDone;
+            // kDone: already evaluated, or no legal member (0xffffffff)
+            const bool take = !(v & kDone) && (pass == 0 ? lb_bin(v) <= pb : v <= best_sad);
+            // one LDS atomic per wave: the wave's takers get consecutive slots
+            const unsigned long long tm = __ballot(take);
+            int wbase = 0;
+            if (lane == 0 && tm) wbase = atomicAdd(&list_n, (int)__popcll(tm));
+            wbase = __shfl(wbase, 0);
+            if (take) {
+                list[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)gi;
+                glb[gi] = v | kDone;
+            }
+        }
+        __syncthreads();
+        const int n = list_n;
+        st_[pass] = (uint32_t)n;
+        SEA_MARK(5)
+        // ---- exact SADs: 128 groups at a time; a lane = one group (4 dx at one dy) x 16 rows ----
+        for (int base = 0; base < n; base += 128) {
+            const uint32_t cur_best = (uint32_t)(best_key >> 32);
+            {
+                const int li = base + set * 64 + lane;
+                const bool have = li < n;
+                const int gi = list[have ? li : n - 1];
+                // the bound may have been overtaken since scheduling: whole waves skip, lanes ride along
+                const bool need = have && (glb[gi] & ~kDone) <= cur_best;
+                st_[2] += (qtr == 0) ? (uint32_t)__popcll(__ballot(need)) : 0u;
+                if (__ballot(need) != 0ull) {  // wave-uniform
+                    const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+                    const uint32_t *wrow = win + (dyi + 16 * qtr) * L.pitch + gx;
+                    const uint32_t *crow = cbase + (16 * qtr) * cstr;
+                    uint32_t acc32[4] = {0u, 0u, 0u, 0u};
+                    // two-row software pipeline: the loads of row r+1 (17 window dwords by ds_read2,
+                    // 16 current dwords by s_load) are in flight while row r's sixteen qsads issue
+                    uint32_t dA[17], dB[17], SA[16], SB[16];
+                    uint64_t acc16 = 0;
+#define SEA_LOAD(r, d, S)                                                   \
+    {                                                                       \
+        const uint32_t *p_ = wrow + (r) * L.pitch;                          \
+        _Pragma("unroll") for (int k = 0; k < 17; k++) d[k] = p_[k];        \
+        _Pragma("unroll") for (int k = 0; k < 16; k++) S[k] = crow[(r) * cstr + k]; \
+    }
+#define SEA_ROW(d, S)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 16; k++)                                                     \
+        acc16 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], S[k], acc16);
+                    SEA_LOAD(0, dA, SA)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): row r has landed ...
+                        SEA_LOAD(r + 1, dB, SB)              // ... row r+1 goes out before row r's qsads
+                        __builtin_amdgcn_sched_barrier(0);
+                        SEA_ROW(dA, SA)
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        if (r + 2 < 16) SEA_LOAD(r + 2, dA, SA)
+                        __builtin_amdgcn_sched_barrier(0);
+                        SEA_ROW(dB, SB)
+                        __builtin_amdgcn_sched_barrier(0);
+                        if ((r & 3) == 2) {  // every 4 rows: 64 qsads * 1020 < 2^16
+#pragma unroll
+                            for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
+                            acc16 = 0;
+                        }
+                    }
+#undef SEA_LOAD
+#undef SEA_ROW
+                    *reinterpret_cast<uint4 *>(&part[(wave * 64 + lane) * 4]) = make_uint4(acc32[0], acc32[1], acc32[2], acc32[3]);
+                }
+            }
+            __syncthreads();
+            if (tid < 128) {  // waves 0 and 1 combine the four row quarters of set 0 and set 1
+                const int li = base + tid;
+                const bool have = li < n;
+                const int gi = list[have ? li : n - 1];
+                const bool need = have && (glb[gi] & ~kDone) <= cur_best;
+                if (__ballot(need) != 0ull) {  // same tasks, same best => same decision as the computing waves
+                    unsigned long long k = ~0ull;
+                    if (have) {
+                        const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+                        const int dy = L.dylo + dyi;
+                        uint4 s = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; q4++) {
+                            const uint4 t = *reinterpret_cast<const uint4 *>(&part[((wave * 4 + q4) * 64 + lane) * 4]);
+                            s.x += t.x;
+                            s.y += t.y;
+                            s.z += t.z;
+                            s.w += t.w;
+                        }
+                        const uint32_t sad[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int dx = L.wx0 - cx + 4 * gx + q;
+                            if (dx >= L.dxlo && dx <= L.dxhi) {
+                                const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
+                                k = key < k ? key : k;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned long long other = __shfl_xor(k, o);
+                        k = other < k ? other : k;
+                    }
+                    if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
+                }
+            }
+            __syncthreads();  // the next batch's skip test reads best_key; part[] is reused
+        }
+        __syncthreads();
+        SEA_MARK(6 + pass)
+    }
+    if (stats && lane == 0) {
+        uint32_t *sp = stats + 8 * (((int64_t)blockIdx.z * g.ctus_y + cty) * g.ctus_x + ctx);
+        if (tid == 0) {
+            sp[0] = st_[0];
+            sp[1] = st_[1];
+#pragma unroll
+            for (int i = 3; i < 8; i++) sp[i] = st_[i];
+        }
+        atomicAdd(&sp[2], st_[2]);  // lanes that really needed evaluation
+    }
+    if (tid == 0) {
+        const unsigned long long best = best_key;
+        x265amd_mv mv;
+        const int c = (int)(best & 0xffffffffu);
+        mv.mvx = (int16_t)(c % span - R);
+        mv.mvy = (int16_t)(c / span - R);
+        mv.sad = (uint32_t)(best >> 32);
+        out[((int64_t)f * g.nrefs + rr) * g.ctus_x * g.ctus_y + cty * g.ctus_x + ctx] = mv;
+    }
+}
+
+}  // namespace x265amd
+
+using namespace x265amd;
+
+static uint32_t *g_me_stats = nullptr;
+// debugging aid (not part of the ABI): 8 u32 per workgroup -- groups scheduled in pass 0 / 1, lanes
+// that needed evaluation, and clock64 ticks of window+sums / bounds / schedule / exact pass 0 / pass 1
+extern "C" void x265amd_debug_set_me_stats(uint32_t *d_stats) { g_me_stats = d_stats; }
+
+extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int nframes, int nrefs)
+{
+    if (width <= 0 || height <= 0 || nframes <= 0 || nrefs <= 0) return 0;
+    return (size_t)2 * sizeof(uint16_t) * width * height * nframes * nrefs;  // H16 + B16 per (frame, ref) plane
+}
+
+extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
+                                         int stride, int ctu, int range, int nframes, int64_t cur_frame_stride,
+                                         int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride,
+                                         x265amd_mv *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    if (!initialised()) return X265AMD_ERR_NOT_INIT;
+    if (!d_cur || !d_ref || !d_out || !d_workspace) return X265AMD_ERR_ARG;
+    if (ctu != 64) return X265AMD_ERR_ARG;
+    if (width <= 0 || height <= 0 || width % 64 || height % 64 || stride < width) return X265AMD_ERR_ARG;
+    if (range < 0 || range > 1024 || nframes < 0 || nrefs < 1) return X265AMD_ERR_ARG;
+    if ((stride & 3) || ((uintptr_t)d_cur & 3) || ((uintptr_t)d_ref & 3) || (cur_frame_stride & 3) ||
+        (ref_frame_stride & 3) || (ref_ref_stride & 3) || ((uintptr_t)d_workspace & 15))
+        return X265AMD_ERR_ARG;
+    if (nframes == 0) return X265AMD_OK;
+    const int64_t nplanes = (int64_t)nframes * nrefs;
+    if (nplanes > 65535) return X265AMD_ERR_ARG;
+    if (workspace_bytes < x265amd_me_workspace_bytes(width, height, nframes, nrefs)) return X265AMD_ERR_ARG;
+
+    // LDS: window + group bounds + schedule list, sized for the largest CTU neighbourhood
+    int max_rows = 0, max_pitch = 0, max_ngx = 0, max_ndy = 0;
+    for (int cy = 0; cy < height; cy += 64) {
+        const SeaLayout L = sea_layout(width, height, range, 0, cy);
+        max_rows = L.win_rows > max_rows ? L.win_rows : max_rows;
+        max_ndy = L.ndy > max_ndy ? L.ndy : max_ndy;
+    }
+    for (int cx = 0; cx < width; cx += 64) {
+        const SeaLayout L = sea_layout(width, height, range, cx, 0);
+        max_pitch = L.pitch > max_pitch ? L.pitch : max_pitch;
+        max_ngx = L.ngx > max_ngx ? L.ngx : max_ngx;
+    }
+    const int max_groups = max_ngx * max_ndy;
+    if (max_groups > 65535) return X265AMD_ERR_LDS;  // the schedule list holds 16-bit group indices
+    const int win_dwords = max_rows * max_pitch;
+    const size_t lds = (size_t)win_dwords * 4 + (size_t)max_groups * 4 + (((size_t)max_groups * 2 + 15) & ~(size_t)15);
+    if (lds + 9216 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;  // + the kernel's static LDS
+
+    uint16_t *hbuf = (uint16_t *)d_workspace;
+    uint16_t *bbuf = hbuf + (size_t)nplanes * width * height;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(box16_h, dim3((width / 4 + 255) / 256, height, (unsigned)nplanes), dim3(256), 0, st, d_ref, hbuf,
+                       width, height, stride, nrefs, ref_frame_stride, ref_ref_stride);
+    hipLaunchKernelGGL(box16_v, dim3((width / 2 + 255) / 256, (height + kBoxVRows - 1) / kBoxVRows, (unsigned)nplanes),
+                       dim3(256), 0, st, hbuf, bbuf, width, height);
+    MeGeom g;
+    g.width = width;
+    g.height = height;
+    g.stride = stride;
+    g.range = range;
+    g.nrefs = nrefs;
+    g.ctus_x = width / 64;
+    g.ctus_y = height / 64;
+    g.cur_fs = cur_frame_stride;
+    g.ref_fs = ref_frame_stride;
+    g.ref_rs = ref_ref_stride;
+    X265AMD_HIP(hipFuncSetAttribute((const void *)me_sea_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(me_sea_kernel, dim3(g.ctus_x, g.ctus_y, (unsigned)nplanes), dim3(kSeaThreads), lds, st, d_cur, d_ref, bbuf,
+                       d_out, g, max_groups, win_dwords, g_me_stats);
+    return hip_status(hipGetLastError());
+}

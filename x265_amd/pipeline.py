@@ -15,7 +15,7 @@ from . import api
 
 class MeTqPipeline:
     def __init__(self, frames, ctu=64, search_range=64, nrefs=1, tu=32, qp=32, slice_type=api.SLICE_P,
-                 device=None):
+                 method="sea"):
         """frames: uint8 tensor [F+nrefs][H][W] on the GPU (H, W multiples of ctu).  Frames
         nrefs..F+nrefs-1 are encoded; frame i uses frames i-1..i-nrefs as references."""
         if frames.dim() != 3 or frames.dtype != torch.uint8 or not frames.is_cuda:
@@ -37,17 +37,27 @@ class MeTqPipeline:
         self.level = torch.empty((self.nframes, h, w), dtype=torch.int16, device=dev)
         self.abs_sum = torch.empty((self.nframes, (h // tu) * (w // tu)), dtype=torch.int32, device=dev)
         self.rec = torch.empty((self.nframes, h, w), dtype=torch.uint8, device=dev)
+        self.method = method
+        self.workspace = None
+        if method == "sea":
+            self.workspace = torch.empty(max(api.me_workspace_bytes(w, h, self.nframes, nrefs), 16), dtype=torch.uint8,
+                                         device=dev)
         self._mv0 = torch.empty((self.nframes, self.nctu, 2), dtype=torch.int32, device=dev) if nrefs > 1 else None
 
     def motion_search(self):
-        if self.nrefs > 1:
-            fs = self.frames.stride(0)
-            base = self.frames.data_ptr() + (self.nrefs - 1) * fs
-            api._check(api._lib().x265amd_me_fullsearch(
-                self.cur.data_ptr(), base, self.w, self.h, self.frames.stride(1), self.ctu, self.range, self.nframes,
-                fs, fs, self.nrefs, -fs, self.mv.data_ptr(), api._stream()), "x265amd_me_fullsearch")
-        else:
-            api.me_fullsearch(self.cur, self.refs, self.ctu, self.range, out=self.mv)
+        fs = self.frames.stride(0)
+        base = self.frames.data_ptr() + (self.nrefs - 1) * fs   # ref(f, r) = base + f*fs - r*fs
+        args = (self.cur.data_ptr(), base, self.w, self.h, self.frames.stride(1), self.ctu, self.range, self.nframes,
+                fs, fs, self.nrefs, -fs, self.mv.data_ptr())
+        if self.method == "sea":
+            st = api._lib().x265amd_me_fullsearch_sea(*args, self.workspace.data_ptr(), self.workspace.numel(),
+                                                      api._stream())
+            if st == -5:  # X265AMD_ERR_LDS: window + bounds do not fit (R = 128): exhaustive kernel
+                self.method = "brute"
+            else:
+                api._check(st, "x265amd_me_fullsearch_sea")
+                return self.mv
+        api._check(api._lib().x265amd_me_fullsearch(*args, api._stream()), "x265amd_me_fullsearch")
         return self.mv
 
     def best_ref_mv(self):
