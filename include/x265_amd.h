@@ -125,8 +125,9 @@ int x265amd_me_fullsearch(const uint8_t *d_cur, const uint8_t *d_ref, int width,
  * |sum(cur) - sum(ref)|) exceeds the SAD of a candidate already evaluated, so
  * the first strict minimum of src/encode.cpp:762-765 is untouched.  Needs a
  * caller-provided device workspace of x265amd_me_workspace_bytes() bytes
- * (16-byte aligned) for the reference box sums; ctu must be 64. */
-size_t x265amd_me_workspace_bytes(int width, int height, int nframes, int nrefs);
+ * (16-byte aligned) for the reference box sums, the per-group bounds and the
+ * first-batch schedule; ctu must be 64. */
+size_t x265amd_me_workspace_bytes(int width, int height, int range, int nframes, int nrefs);
 int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
                               int stride, int ctu, int range, int nframes,
                               int64_t cur_frame_stride, int64_t ref_frame_stride, int nrefs,

@@ -19,7 +19,7 @@ mv = x265_amd.me_fullsearch(fr[1:], fr[:-1], 64, R, method="sea")
 torch.cuda.synchronize()
 lib.x265amd_debug_set_me_stats(None)
 s = stats.cpu().numpy().astype(np.int64)[0]
-names = ["n_pass0", "n_pass1", "lanes_needed", "t_window", "t_bounds", "t_sched", "t_exact0", "t_exact1"]
+names = ["n_pass0", "n_pass1"]
 for i, n in enumerate(names):
     print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
 interior = [i for i in range(nctu) if 2 <= i % 30 <= 27 and 2 <= i // 30 <= 14]

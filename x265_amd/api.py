@@ -61,7 +61,7 @@ SIGNATURES = {
     "x265amd_me_fullsearch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
-    "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -155,8 +155,8 @@ def sad_blocks(w, n, src, stride_src, ref, stride_ref, src_off, ref_off):
 # --------------------------------------------------------------------------
 # motion search
 # --------------------------------------------------------------------------
-def me_workspace_bytes(width, height, nframes, nrefs):
-    return int(_lib().x265amd_me_workspace_bytes(width, height, nframes, nrefs))
+def me_workspace_bytes(width, height, search_range, nframes, nrefs):
+    return int(_lib().x265amd_me_workspace_bytes(width, height, search_range, nframes, nrefs))
 
 
 def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", workspace=None):
@@ -184,7 +184,7 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
         raise ValueError("method")
     use_sea = method == "sea" or (method == "auto" and ctu == 64 and w > 0 and h > 0 and w % 64 == 0 and h % 64 == 0)
     if use_sea:
-        need = me_workspace_bytes(w, h, f, nrefs)
+        need = me_workspace_bytes(w, h, search_range, f, nrefs)
         if workspace is None:
             workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=cur.device)
         _dev(workspace, torch.uint8, "workspace")

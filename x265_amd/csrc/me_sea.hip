@@ -11,13 +11,16 @@
 // 64-bit key (sad << 32 | raster index) over what was evaluated -- the
 // reference's "first strict minimum" (src/encode.cpp:762-765).
 //
-// Three kernels:
+// Four kernels:
 //   box16_h / box16_v : B16[y][x] = sum of the 16x16 reference block at (x, y), u16
 //                       (16*16*255 < 2^16), separable, coalesced, HBM-bound;
-//   me_sea_kernel     : per (CTU, ref, frame) workgroup -- window to LDS, bounds for
-//                       every legal candidate (v_sad_u32 against the CTU's own
-//                       sub-block sums), histogram pick of a first batch, exact
-//                       SADs, then everything whose bound is still <= best.
+//   sea_bounds_kernel : per (CTU, ref, frame) workgroup, small LDS, high occupancy -- bounds for
+//                       every legal candidate (v_sad_u32 against the CTU's own sub-block
+//                       sums), histogram pick of a first batch;
+//   sea_exact_kernel  : window to LDS, exact SADs of the first batch, then of everything
+//                       whose bound is still <= best.
+#include <stdlib.h>
+
 #include "common.h"
 #include "me_common.h"
 
@@ -99,7 +102,6 @@ __host__ __device__ inline SeaLayout sea_layout(int w, int h, int range, int cx,
 }
 
 constexpr int kBins = 96;         // quarter-octave bins of the bound: covers 24 octaves
-constexpr uint32_t kDone = 0x80000000u;
 
 __device__ __forceinline__ int lb_bin(uint32_t lb)
 {
@@ -108,73 +110,45 @@ __device__ __forceinline__ int lb_bin(uint32_t lb)
     return 4 * (msb - 1) + (int)((lb >> (msb - 2)) & 3u);  // lb=4 -> 4, monotone, < 96 for lb < 2^24
 }
 
-constexpr int kSeaThreads = 512;  // 8 waves; two workgroups per CU => 4 waves per SIMD hide the bound loads
+constexpr int kMaxChain = 20;     // chain steps of 16 rows: ndy <= 257 (R <= 128) needs 17
+constexpr int kSeaThreads = 512;  // 8 waves
+constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or already scheduled
 
-__global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *__restrict__ cur_base,
-                                                                const uint8_t *__restrict__ ref_base,
-                                                                const uint16_t *__restrict__ bbuf,
-                                                                x265amd_mv *__restrict__ out, const MeGeom g,
-                                                                int max_groups, int win_dwords,
-                                                                uint32_t *__restrict__ stats)
+// Bounds are kept as u16 = floor(LB / 16) (LB <= 16 * 65280): still a lower bound, 15 units coarser.
+__device__ __forceinline__ uint32_t lb_store(uint32_t lb) { return lb >> 4; }
+
+struct SeaHdr {  // per (plane, CTU)
+    uint32_t n0;  // groups in the first batch
+    uint32_t pad[3];
+};
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 1: bounds.  No window, 9 KB of LDS => high occupancy hides the box-sum loads.
+//   out: gl[plane][ctu][max_groups] u16 bound per group (kNone where scheduled / illegal),
+//        list0[plane][ctu][..] the first batch (lowest histogram bins until >= 256 groups), hdr.n0
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
+                                                                 const uint16_t *__restrict__ bbuf,
+                                                                 uint16_t *__restrict__ gl, uint16_t *__restrict__ list0,
+                                                                 SeaHdr *__restrict__ hdr, const MeGeom g, int max_groups)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *win = smem;                       // [win_rows][pitch] reference window
-    uint32_t *glb = smem + win_dwords;          // [ndy][ngx] bound of each 4-candidate group (min over its legal members)
-    uint16_t *list = reinterpret_cast<uint16_t *>(glb + max_groups);  // groups scheduled for exact evaluation
-    __shared__ __attribute__((aligned(16))) uint32_t part[8 * 64 * 4];  // partial SADs: [wave][lane][4 dx]
+    uint16_t *glb = reinterpret_cast<uint16_t *>(smem);  // [ndy][ngx]
     __shared__ uint32_t hist[kBins];
-    __shared__ uint32_t csum[16];               // the CTU's own sixteen 16x16 sums
-    __shared__ unsigned long long best_key;
+    __shared__ uint32_t csum[16];
     __shared__ int list_n, pick_bin;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: keeps the current rows in SGPRs
     const int ctx = blockIdx.x, cty = blockIdx.y;
-    const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
+    const int f = blockIdx.z / g.nrefs;
     const int cx = ctx * 64, cy = cty * 64;
-    const int R = g.range;
-    const SeaLayout L = sea_layout(g.width, g.height, R, cx, cy);
+    const SeaLayout L = sea_layout(g.width, g.height, g.range, cx, cy);
     const uint8_t *cur = cur_base + f * g.cur_fs;
-    const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
     const uint16_t *B = bbuf + (int64_t)blockIdx.z * g.height * g.width;
-    const int span = 2 * R + 1;
+    const int64_t ctu_id = ((int64_t)blockIdx.z * g.ctus_y + cty) * g.ctus_x + ctx;
 
-    long long tmark = stats ? clock64() : 0;
-    uint32_t st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define SEA_MARK(i)                                     \
-    if (stats) {                                        \
-        const long long now_ = clock64();               \
-        st_[i] += (uint32_t)(now_ - tmark);             \
-        tmark = now_;                                   \
-    }
-    // ---- stage the reference window (exact SADs need it): a wave per row, a lane per dword,
-    //      four rows in flight ----
-    for (int qb = 0; qb < L.pitch; qb += 64) {
-        const int wq = qb + lane;
-        const int gx = L.wx0 + 4 * wq;
-        const bool colok = wq < L.pitch;
-        const bool inpic = colok && gx + 4 <= g.width;
-        for (int row0 = wave; row0 < L.win_rows; row0 += 32) {
-            uint32_t v[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = row0 + 8 * j, gy = cy + L.dylo + row;
-                v[j] = 0;  // outside the picture: only ever paired with candidates that are masked below
-                if (inpic && row < L.win_rows && gy < g.height)
-                    v[j] = *reinterpret_cast<const uint32_t *>(ref + (int64_t)gy * g.stride + gx);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int row = row0 + 8 * j;
-                if (colok && row < L.win_rows) win[row * L.pitch + wq] = v[j];
-            }
-        }
-    }
     if (tid < kBins) hist[tid] = 0;
-    if (tid == 0) {
-        best_key = ~0ull;
-        list_n = 0;
-    }
+    if (tid == 0) list_n = 0;
     // ---- the CTU's sub-block sums: 16 lanes per sub-block, one 16-pixel row each ----
     if (tid < 256) {
         const int b = tid >> 4, rrow = tid & 15;
@@ -188,15 +162,14 @@ __global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *_
         if (rrow == 0) csum[b] = s;
     }
     __syncthreads();
-    SEA_MARK(3)
     uint32_t cs[16];
 #pragma unroll
     for (int b = 0; b < 16; b++) cs[b] = __builtin_amdgcn_readfirstlane(csum[b]);
 
     // ---- bounds.  Group = 4 window-aligned dx at one dy.  The bound of the group at row dyi needs the
     //      box sums of rows dyi, dyi+16, dyi+32, dyi+48 -- and so do its neighbours 16 rows up and
-    //      down.  A lane therefore walks a CHAIN dyi = c, c+16, c+32, .. at fixed gx and keeps the four
-    //      row bands in registers: 4 eight-byte loads per group instead of 16 (coalesced along gx). ----
+    //      down.  A lane therefore walks a CHAIN dyi = c, c+16, c+32, .. at fixed gx and keeps the row
+    //      bands in registers: 4 eight-byte loads per group instead of 16 (coalesced along gx). ----
     const int a = cx + L.dxlo - L.wx0;  // window column of dxlo
     const int ndx = L.dxhi - L.dxlo + 1;
     {
@@ -212,42 +185,47 @@ __global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *_
                 const int dxi = 4 * gx + q - a;
                 if (dxi >= 0 && dxi < ndx) legal |= 1u << q;
             }
-            uint2 bnd[4][4];  // [band j][k]
+            // five band registers used round-robin: while step m is being summed, band m+4 is in flight
+            uint2 bnd[5][4];
 #pragma unroll
-            for (int j = 0; j < 3; j++)
+            for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) bnd[j + 1][k] = *reinterpret_cast<const uint2 *>(bp + j * band + 16 * k);
-            for (int dyi = c, m = 0; dyi < L.ndy; dyi += 16, m++) {
+                for (int k = 0; k < 4; k++) bnd[j][k] = *reinterpret_cast<const uint2 *>(bp + j * band + 16 * k);
+            for (int m0 = 0; m0 < kMaxChain; m0 += 5)  // unrolled by the rotation period: static register indices
 #pragma unroll
-                for (int j = 0; j < 3; j++)
+                for (int mm = 0; mm < 5; mm++) {
+                    const int m = m0 + mm;
+                    const int dyi = c + 16 * m;
+                    if (dyi >= L.ndy) break;
+                    if (dyi + 16 < L.ndy) {
 #pragma unroll
-                    for (int k = 0; k < 4; k++) bnd[j][k] = bnd[j + 1][k];
-#pragma unroll
-                for (int k = 0; k < 4; k++) bnd[3][k] = *reinterpret_cast<const uint2 *>(bp + (m + 3) * band + 16 * k);
-                uint32_t lb[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const uint2 v = bnd[j][k];
-                        const uint32_t sc = cs[4 * j + k];
-                        const uint32_t v0 = v.x & 0xffffu, v1 = v.x >> 16, v2 = v.y & 0xffffu, v3 = v.y >> 16;
-                        lb[0] += v0 > sc ? v0 - sc : sc - v0;  // v_sad_u32
-                        lb[1] += v1 > sc ? v1 - sc : sc - v1;
-                        lb[2] += v2 > sc ? v2 - sc : sc - v2;
-                        lb[3] += v3 > sc ? v3 - sc : sc - v3;
+                        for (int k = 0; k < 4; k++)
+                            bnd[(mm + 4) % 5][k] = *reinterpret_cast<const uint2 *>(bp + (m + 4) * band + 16 * k);
                     }
-                uint32_t mn = 0xffffffffu;
+                    uint32_t lb[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (legal & (1u << q)) mn = min(mn, lb[q]);
-                glb[dyi * L.ngx + gx] = mn;
-                if (mn != 0xffffffffu) atomicAdd(&hist[lb_bin(mn)], 1u);
-            }
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint2 v = bnd[(mm + j) % 5][k];
+                            const uint32_t sc = cs[4 * j + k];
+                            const uint32_t v0 = v.x & 0xffffu, v1 = v.x >> 16, v2 = v.y & 0xffffu, v3 = v.y >> 16;
+                            lb[0] += v0 > sc ? v0 - sc : sc - v0;  // v_sad_u32
+                            lb[1] += v1 > sc ? v1 - sc : sc - v1;
+                            lb[2] += v2 > sc ? v2 - sc : sc - v2;
+                            lb[3] += v3 > sc ? v3 - sc : sc - v3;
+                        }
+                    uint32_t mn = 0xffffffffu;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (legal & (1u << q)) mn = min(mn, lb[q]);
+                    const uint32_t st = mn == 0xffffffffu ? kNone : lb_store(mn);
+                    glb[dyi * L.ngx + gx] = (uint16_t)st;
+                    if (st != kNone) atomicAdd(&hist[lb_bin(st)], 1u);
+                }
         }
     }
     __syncthreads();
-    SEA_MARK(4)
 
     // ---- first batch: the lowest bins until at least 256 groups ----
     if (tid < 64) {
@@ -270,49 +248,138 @@ __global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *_
         if (tid == 0) pick_bin = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : kBins);
     }
     __syncthreads();
+    const int pb = pick_bin;
+
+    // ---- write the bounds out; groups of the first batch go to list0 (scan order) and are marked ----
+    uint16_t *glo = gl + ctu_id * max_groups;
+    uint16_t *lo = list0 + ctu_id * max_groups;
+    for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
+        const int gi = g0 + tid;
+        const uint32_t v = gi < L.ngroups ? (uint32_t)glb[gi] : kNone;
+        const bool take = v != kNone && lb_bin(v) <= pb;
+        const unsigned long long tm = __ballot(take);
+        int wbase = 0;
+        if (lane == 0 && tm) wbase = atomicAdd(&list_n, (int)__popcll(tm));
+        wbase = __shfl(wbase, 0);
+        if (take) {
+            const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+            lo[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)((dyi << 7) | gx);
+        }
+        if (gi < L.ngroups) glo[gi] = take ? (uint16_t)kNone : (uint16_t)v;
+    }
+    __syncthreads();
+    if (tid == 0) hdr[ctu_id].n0 = (uint32_t)list_n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel 2: exact SADs.  Window in LDS; first batch from list0, then everything whose bound is
+// still <= best (one scan of the u16 bounds), 128 groups at a time: a lane = one group (4 dx at one
+// dy) x 16 rows, 8 waves = 2 sets of 64 groups x 4 row quarters, partial sums merged through LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t *__restrict__ cur_base,
+                                                                   const uint8_t *__restrict__ ref_base,
+                                                                   const uint16_t *__restrict__ gl,
+                                                                   const uint16_t *__restrict__ list0,
+                                                                   const SeaHdr *__restrict__ hdr,
+                                                                   x265amd_mv *__restrict__ out, const MeGeom g,
+                                                                   int max_groups, int win_dwords,
+                                                                   uint32_t *__restrict__ stats)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *win = smem;                                                     // [win_rows][pitch] reference window
+    uint16_t *list = reinterpret_cast<uint16_t *>(smem + win_dwords);         // second-pass schedule
+    __shared__ __attribute__((aligned(16))) uint32_t part[8 * 64 * 4];        // partial SADs: [wave][lane][4 dx]
+    __shared__ unsigned long long best_key;
+    __shared__ int list_n;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: keeps the current rows in SGPRs
+    const int ctx = blockIdx.x, cty = blockIdx.y;
+    const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
+    const int cx = ctx * 64, cy = cty * 64;
+    const int R = g.range;
+    const SeaLayout L = sea_layout(g.width, g.height, R, cx, cy);
+    const uint8_t *cur = cur_base + f * g.cur_fs;
+    const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
+    const int span = 2 * R + 1;
+    const int64_t ctu_id = ((int64_t)blockIdx.z * g.ctus_y + cty) * g.ctus_x + ctx;
+    const uint16_t *glo = gl + ctu_id * max_groups;
+    const uint16_t *l0 = list0 + ctu_id * max_groups;
+
+    // ---- stage the reference window: a wave per row, a lane per dword, 13 rows in flight ----
+    constexpr int kWinInFlight = 13;
+    for (int qb = 0; qb < L.pitch; qb += 64) {
+        const int wq = qb + lane;
+        const int gx = L.wx0 + 4 * wq;
+        const bool colok = wq < L.pitch;
+        const bool inpic = colok && gx + 4 <= g.width;
+        for (int row0 = wave; row0 < L.win_rows; row0 += 8 * kWinInFlight) {
+            uint32_t v[kWinInFlight];
+#pragma unroll
+            for (int j = 0; j < kWinInFlight; j++) {
+                const int row = row0 + 8 * j, gy = cy + L.dylo + row;
+                v[j] = 0;  // outside the picture: only ever paired with candidates that are masked below
+                if (inpic && row < L.win_rows && gy < g.height)
+                    v[j] = *reinterpret_cast<const uint32_t *>(ref + (int64_t)gy * g.stride + gx);
+            }
+#pragma unroll
+            for (int j = 0; j < kWinInFlight; j++) {
+                const int row = row0 + 8 * j;
+                if (colok && row < L.win_rows) win[row * L.pitch + wq] = v[j];
+            }
+        }
+    }
+    if (tid == 0) {
+        best_key = ~0ull;
+        list_n = 0;
+    }
+    const int n0 = (int)hdr[ctu_id].n0;
+    __syncthreads();
 
     const uint32_t *__restrict__ cbase = reinterpret_cast<const uint32_t *>(cur + (int64_t)cy * g.stride + cx);
     const int cstr = g.stride >> 2;
-    const int set = wave >> 2, qtr = wave & 3;  // exact phase: 2 sets of 64 groups x 4 row quarters
+    const int set = wave >> 2, qtr = wave & 3;
+    int n1 = 0;
 
     for (int pass = 0; pass < 2; pass++) {
-        // ---- schedule: pass 0 = the picked bins; pass 1 = everything not yet done whose bound <= best ----
-        const uint32_t best_sad = (uint32_t)(best_key >> 32);
-        const int pb = pick_bin;
-        __syncthreads();
-        if (tid == 0) list_n = 0;
-        __syncthreads();
-        for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
-            const int gi = g0 + tid;
-            const uint32_t v = gi < L.ngroups ? glb[gi] : kDone;
-            // kDone: already evaluated, or no legal member (0xffffffff)
-            const bool take = !(v & kDone) && (pass == 0 ? lb_bin(v) <= pb : v <= best_sad);
-            // one LDS atomic per wave: the wave's takers get consecutive slots
-            const unsigned long long tm = __ballot(take);
-            int wbase = 0;
-            if (lane == 0 && tm) wbase = atomicAdd(&list_n, (int)__popcll(tm));
-            wbase = __shfl(wbase, 0);
-            if (take) {
-                list[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)gi;
-                glb[gi] = v | kDone;
+        int n = n0;
+        if (pass == 1) {
+            // ---- everything not yet scheduled whose bound is <= best: sweep 1 counts the wave's takers,
+            //      ONE LDS atomic reserves their slots, sweep 2 fills them in scan order ----
+            const uint32_t best_sad = (uint32_t)(best_key >> 32);
+            int wcount = 0;
+            for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
+                const int gi = g0 + tid;
+                const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
+                wcount += (int)__popcll(__ballot(v != kNone && (v << 4) <= best_sad));
             }
+            int wbase = 0;
+            if (lane == 0 && wcount) wbase = atomicAdd(&list_n, wcount);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (wcount) {
+                for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
+                    const int gi = g0 + tid;
+                    const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
+                    const bool take = v != kNone && (v << 4) <= best_sad;
+                    const unsigned long long tm = __ballot(take);
+                    if (take) {
+                        const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+                        list[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)((dyi << 7) | gx);
+                    }
+                    wbase += (int)__popcll(tm);
+                }
+            }
+            __syncthreads();
+            n = list_n;
+            n1 = n;
         }
-        __syncthreads();
-        const int n = list_n;
-        st_[pass] = (uint32_t)n;
-        SEA_MARK(5)
-        // ---- exact SADs: 128 groups at a time; a lane = one group (4 dx at one dy) x 16 rows ----
         for (int base = 0; base < n; base += 128) {
-            const uint32_t cur_best = (uint32_t)(best_key >> 32);
             {
                 const int li = base + set * 64 + lane;
                 const bool have = li < n;
-                const int gi = list[have ? li : n - 1];
-                // the bound may have been overtaken since scheduling: whole waves skip, lanes ride along
-                const bool need = have && (glb[gi] & ~kDone) <= cur_best;
-                st_[2] += (qtr == 0) ? (uint32_t)__popcll(__ballot(need)) : 0u;
-                if (__ballot(need) != 0ull) {  // wave-uniform
-                    const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+                const int ent = pass == 0 ? (int)l0[have ? li : n - 1] : (int)list[have ? li : n - 1];
+                const int dyi = ent >> 7, gx = ent & 127;
+                if (__ballot(have) != 0ull) {  // wave-uniform
                     const uint32_t *wrow = win + (dyi + 16 * qtr) * L.pitch + gx;
                     const uint32_t *crow = cbase + (16 * qtr) * cstr;
                     uint32_t acc32[4] = {0u, 0u, 0u, 0u};
@@ -357,12 +424,11 @@ __global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *_
             if (tid < 128) {  // waves 0 and 1 combine the four row quarters of set 0 and set 1
                 const int li = base + tid;
                 const bool have = li < n;
-                const int gi = list[have ? li : n - 1];
-                const bool need = have && (glb[gi] & ~kDone) <= cur_best;
-                if (__ballot(need) != 0ull) {  // same tasks, same best => same decision as the computing waves
+                if (__ballot(have) != 0ull) {
                     unsigned long long k = ~0ull;
                     if (have) {
-                        const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+                        const int ent = pass == 0 ? (int)l0[li] : (int)list[li];
+                        const int dyi = ent >> 7, gx = ent & 127;
                         const int dy = L.dylo + dyi;
                         uint4 s = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
@@ -391,20 +457,9 @@ __global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *_
                     if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
                 }
             }
-            __syncthreads();  // the next batch's skip test reads best_key; part[] is reused
+            __syncthreads();  // part[] is reused; best_key is read after the pass
         }
         __syncthreads();
-        SEA_MARK(6 + pass)
-    }
-    if (stats && lane == 0) {
-        uint32_t *sp = stats + 8 * (((int64_t)blockIdx.z * g.ctus_y + cty) * g.ctus_x + ctx);
-        if (tid == 0) {
-            sp[0] = st_[0];
-            sp[1] = st_[1];
-#pragma unroll
-            for (int i = 3; i < 8; i++) sp[i] = st_[i];
-        }
-        atomicAdd(&sp[2], st_[2]);  // lanes that really needed evaluation
     }
     if (tid == 0) {
         const unsigned long long best = best_key;
@@ -414,6 +469,10 @@ __global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *_
         mv.mvy = (int16_t)(c / span - R);
         mv.sad = (uint32_t)(best >> 32);
         out[((int64_t)f * g.nrefs + rr) * g.ctus_x * g.ctus_y + cty * g.ctus_x + ctx] = mv;
+        if (stats) {
+            stats[8 * ctu_id + 0] = (uint32_t)n0;
+            stats[8 * ctu_id + 1] = (uint32_t)n1;
+        }
     }
 }
 
@@ -422,14 +481,37 @@ __global__ __launch_bounds__(kSeaThreads, 4) void me_sea_kernel(const uint8_t *_
 using namespace x265amd;
 
 static uint32_t *g_me_stats = nullptr;
-// debugging aid (not part of the ABI): 8 u32 per workgroup -- groups scheduled in pass 0 / 1, lanes
-// that needed evaluation, and clock64 ticks of window+sums / bounds / schedule / exact pass 0 / pass 1
+// debugging aid (not part of the ABI): 8 u32 per workgroup; [0] / [1] = groups evaluated in pass 0 / 1
 extern "C" void x265amd_debug_set_me_stats(uint32_t *d_stats) { g_me_stats = d_stats; }
 
-extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int nframes, int nrefs)
+// largest per-CTU geometry of a picture: rows / pitch of the window, groups per row, rows of candidates
+static void sea_extents(int width, int height, int range, int &max_rows, int &max_pitch, int &max_ngx, int &max_ndy)
 {
-    if (width <= 0 || height <= 0 || nframes <= 0 || nrefs <= 0) return 0;
-    return (size_t)2 * sizeof(uint16_t) * width * height * nframes * nrefs;  // H16 + B16 per (frame, ref) plane
+    max_rows = max_pitch = max_ngx = max_ndy = 0;
+    for (int cy = 0; cy < height; cy += 64) {
+        const SeaLayout L = sea_layout(width, height, range, 0, cy);
+        max_rows = L.win_rows > max_rows ? L.win_rows : max_rows;
+        max_ndy = L.ndy > max_ndy ? L.ndy : max_ndy;
+    }
+    for (int cx = 0; cx < width; cx += 64) {
+        const SeaLayout L = sea_layout(width, height, range, cx, 0);
+        max_pitch = L.pitch > max_pitch ? L.pitch : max_pitch;
+        max_ngx = L.ngx > max_ngx ? L.ngx : max_ngx;
+    }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, int nframes, int nrefs)
+{
+    if (width <= 0 || height <= 0 || range < 0 || nframes <= 0 || nrefs <= 0 || width % 64 || height % 64) return 0;
+    int max_rows, max_pitch, max_ngx, max_ndy;
+    sea_extents(width, height, range, max_rows, max_pitch, max_ngx, max_ndy);
+    const size_t planes = (size_t)nframes * nrefs, nctu = (size_t)(width / 64) * (height / 64);
+    const size_t per_ctu = (size_t)max_ngx * max_ndy;
+    return align256(2 * sizeof(uint16_t) * width * height * planes)        // H16 + B16 per (frame, ref) plane
+           + 2 * align256(sizeof(uint16_t) * per_ctu * nctu * planes)      // bounds + first-batch list per CTU
+           + align256(sizeof(SeaHdr) * nctu * planes);
 }
 
 extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
@@ -448,28 +530,29 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     if (nframes == 0) return X265AMD_OK;
     const int64_t nplanes = (int64_t)nframes * nrefs;
     if (nplanes > 65535) return X265AMD_ERR_ARG;
-    if (workspace_bytes < x265amd_me_workspace_bytes(width, height, nframes, nrefs)) return X265AMD_ERR_ARG;
+    if (workspace_bytes < x265amd_me_workspace_bytes(width, height, range, nframes, nrefs)) return X265AMD_ERR_ARG;
 
-    // LDS: window + group bounds + schedule list, sized for the largest CTU neighbourhood
-    int max_rows = 0, max_pitch = 0, max_ngx = 0, max_ndy = 0;
-    for (int cy = 0; cy < height; cy += 64) {
-        const SeaLayout L = sea_layout(width, height, range, 0, cy);
-        max_rows = L.win_rows > max_rows ? L.win_rows : max_rows;
-        max_ndy = L.ndy > max_ndy ? L.ndy : max_ndy;
-    }
-    for (int cx = 0; cx < width; cx += 64) {
-        const SeaLayout L = sea_layout(width, height, range, cx, 0);
-        max_pitch = L.pitch > max_pitch ? L.pitch : max_pitch;
-        max_ngx = L.ngx > max_ngx ? L.ngx : max_ngx;
-    }
+    int max_rows, max_pitch, max_ngx, max_ndy;
+    sea_extents(width, height, range, max_rows, max_pitch, max_ngx, max_ndy);
     const int max_groups = max_ngx * max_ndy;
-    if (max_groups > 65535) return X265AMD_ERR_LDS;  // the schedule list holds 16-bit group indices
+    if (max_ngx > 127 || max_ndy > 511 || max_ndy > 16 * kMaxChain) return X265AMD_ERR_LDS;  // 16-bit schedule entries
     const int win_dwords = max_rows * max_pitch;
-    const size_t lds = (size_t)win_dwords * 4 + (size_t)max_groups * 4 + (((size_t)max_groups * 2 + 15) & ~(size_t)15);
-    if (lds + 9216 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;  // + the kernel's static LDS
+    size_t lds_exact = (size_t)win_dwords * 4 + (((size_t)max_groups * 2 + 15) & ~(size_t)15);
+    if (const char *pad = getenv("X265AMD_SEA_LDS_PAD")) lds_exact += (size_t)atoi(pad);  // occupancy experiments only
+    if (lds_exact + 9216 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;  // + the kernel's static LDS
+    const size_t lds_bounds = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
 
-    uint16_t *hbuf = (uint16_t *)d_workspace;
+    const size_t nctu = (size_t)(width / 64) * (height / 64);
+    uint8_t *ws = (uint8_t *)d_workspace;
+    uint16_t *hbuf = (uint16_t *)ws;
     uint16_t *bbuf = hbuf + (size_t)nplanes * width * height;
+    ws += align256(2 * sizeof(uint16_t) * width * height * (size_t)nplanes);
+    uint16_t *gl = (uint16_t *)ws;
+    ws += align256(sizeof(uint16_t) * (size_t)max_groups * nctu * (size_t)nplanes);
+    uint16_t *list0 = (uint16_t *)ws;
+    ws += align256(sizeof(uint16_t) * (size_t)max_groups * nctu * (size_t)nplanes);
+    SeaHdr *hdr = (SeaHdr *)ws;
+
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(box16_h, dim3((width / 4 + 255) / 256, height, (unsigned)nplanes), dim3(256), 0, st, d_ref, hbuf,
                        width, height, stride, nrefs, ref_frame_stride, ref_ref_stride);
@@ -486,8 +569,12 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     g.cur_fs = cur_frame_stride;
     g.ref_fs = ref_frame_stride;
     g.ref_rs = ref_ref_stride;
-    X265AMD_HIP(hipFuncSetAttribute((const void *)me_sea_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(me_sea_kernel, dim3(g.ctus_x, g.ctus_y, (unsigned)nplanes), dim3(kSeaThreads), lds, st, d_cur, d_ref, bbuf,
-                       d_out, g, max_groups, win_dwords, g_me_stats);
+    const dim3 grid(g.ctus_x, g.ctus_y, (unsigned)nplanes);
+    hipLaunchKernelGGL(sea_bounds_kernel, grid, dim3(kSeaThreads), lds_bounds, st, d_cur, bbuf, gl, list0, hdr, g,
+                       max_groups);
+    X265AMD_HIP(hipFuncSetAttribute((const void *)sea_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_exact));
+    hipLaunchKernelGGL(sea_exact_kernel, grid, dim3(kSeaThreads), lds_exact, st, d_cur, d_ref, gl, list0, hdr, d_out, g,
+                       max_groups, win_dwords, g_me_stats);
     return hip_status(hipGetLastError());
 }

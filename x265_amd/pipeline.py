@@ -40,7 +40,7 @@ class MeTqPipeline:
         self.method = method
         self.workspace = None
         if method == "sea":
-            self.workspace = torch.empty(max(api.me_workspace_bytes(w, h, self.nframes, nrefs), 16), dtype=torch.uint8,
+            self.workspace = torch.empty(max(api.me_workspace_bytes(w, h, search_range, self.nframes, nrefs), 16), dtype=torch.uint8,
                                          device=dev)
         self._mv0 = torch.empty((self.nframes, self.nctu, 2), dtype=torch.int32, device=dev) if nrefs > 1 else None
 
