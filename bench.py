@@ -163,6 +163,28 @@ def main():
     me_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     tq_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
+    # per-kernel split of the search stage (library-side HIP events on the launch stream), taken right
+    # after the timed region on a few more passes of the same batch: the events are read back per pass
+    kernels_ms = None
+    if pipe.method == "sea" and rank == 0:
+        import ctypes
+        lib = x265_amd.api._lib()
+        lib.x265amd_debug_me_timing.argtypes = [ctypes.c_int]
+        lib.x265amd_debug_me_last_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
+        lib.x265amd_debug_me_timing(1)
+        acc = np.zeros(4)
+        reps = min(args.steps, 10)
+        buf = (ctypes.c_float * 4)()
+        for _ in range(reps):
+            pipe.motion_search()
+            if lib.x265amd_debug_me_last_ms(buf) != 0:
+                acc[:] = np.nan
+                break
+            acc += np.array(buf[:])
+        lib.x265amd_debug_me_timing(0)
+        kernels_ms = dict(zip(["box16_h", "box16_v", "sea_bounds_kernel", "sea_exact_kernel"],
+                              [round(float(x) / reps, 4) for x in acc]))
+
     if rank == 0:
         px_step = nw * nh * fps                      # nominal pixels (1920x1080), SURVEY.md 8d
         value = px_step * world * args.steps / elapsed / 1e6
@@ -202,12 +224,18 @@ def main():
                                    f"full search, {nrefs} ref(s), then {tu}x{tu} DCT+quant+recon QP{qp}; "
                                    f"{fps} frames per step per GPU, frames sharded across GPUs, no collective",
                        "name": args.workload, "frames_per_step_per_gpu": fps, "me_method": pipe.method},
-            "roofline": {"kernel": "me_sea_kernel (+ box16_h/v)" if pipe.method == "sea" else "me_fullsearch_qsad", "bound": "hbm", "achieved": round(achieved, 3),
+            "roofline": {"kernel": "search stage = box16_h + box16_v + sea_bounds_kernel + sea_exact_kernel (dominant)"
+                                   if pipe.method == "sea" else "me_fullsearch_qsad",
+                         "bound": "hbm", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "algorithmic_bytes_per_launch": me_bytes,
-                         "avg_launch_ms": round(me_ms, 4),
-                         "note": "exhaustive SAD search is integer-VALU bound, not HBM bound (SURVEY.md 8d); "
-                                 "see valu"},
+                         "avg_launch_ms": round(me_ms, 4), "kernels_ms": kernels_ms,
+                         "note": "avg_launch_ms = the whole search stage per step (sum of its kernels; compare the "
+                                 "sum of their averages in profiles/*kernel_stats.csv).  Exhaustive SAD search is "
+                                 "integer-VALU bound, not HBM bound (SURVEY.md 8d); see valu.  traffic = PMC "
+                                 "FETCH_SIZE (x2, gfx950) + WRITE_SIZE over the stage's kernels "
+                                 "(profiles/pmc_traffic.json); it counts fabric requests, Infinity-Cache hits "
+                                 "included (window overlap between neighbouring CTUs, box-sum workspace)"},
             "valu": {"pixel_sads_per_launch": sad_ops, "achieved_Tpx_sad_per_s": round(sad_ops / (me_ms * 1e-3) / 1e12, 3),
                      "peak_Tpx_sad_per_s": 152.0,
                      "peak_source": "tools/ubench_valu: v_qsad_pk_u16_u8 issue rate on this chip (profiles/ubench_r1.txt)"},

@@ -8,19 +8,63 @@ import x265_amd
 from x265_amd import synth, api
 x265_amd.init(0)
 W, H, R = 1920, 1088, 64
-seq = np.stack([synth.pad_plane(f, 64) for f in synth.make_sequence(1920, 1080, 3, search_range=R, seed=12345)])
+NF = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+seq = np.stack([synth.pad_plane(f, 64) for f in synth.make_sequence(1920, 1080, NF + 1, search_range=R, seed=12345)])
 fr = torch.from_numpy(seq).cuda()
 nctu = (W // 64) * (H // 64)
-stats = torch.zeros((2, nctu, 8), dtype=torch.int32, device="cuda")
+stats = torch.zeros((NF, nctu, 16), dtype=torch.int32, device="cuda")
 lib = api._lib()
 lib.x265amd_debug_set_me_stats.argtypes = [C.c_void_p]
 lib.x265amd_debug_set_me_stats(stats.data_ptr())
 mv = x265_amd.me_fullsearch(fr[1:], fr[:-1], 64, R, method="sea")
 torch.cuda.synchronize()
 lib.x265amd_debug_set_me_stats(None)
-s = stats.cpu().numpy().astype(np.int64)[0]
-names = ["n_pass0", "n_pass1"]
+s = stats.cpu().numpy().astype(np.int64).reshape(-1, 16)
+nctu_all = s.shape[0]
+names = ["n_pass0", "n_pass1", "cyc_stage", "cyc_pass0", "cyc_pass1"]
 for i, n in enumerate(names):
     print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
-interior = [i for i in range(nctu) if 2 <= i % 30 <= 27 and 2 <= i // 30 <= 14]
+interior = [i for i in range(nctu_all) if 2 <= (i % nctu) % 30 <= 27 and 2 <= (i % nctu) // 30 <= 14]
 print("interior CTUs:", {n: float(s[interior, i].mean()) for i, n in enumerate(names)})
+print("CTUs with a second pass:", int((s[:, 1] > 0).sum()), "of", nctu_all,
+      "| rounds per CTU (mean):", float((np.ceil(s[:, 0] / 128) + np.ceil(s[:, 1] / 128)).mean()))
+print("pass-1 sizes histogram (0, 1-64, 65-128, 129-512, >512):",
+      [int(((s[:, 1] >= a) & (s[:, 1] <= b)).sum()) for a, b in ((0, 0), (1, 64), (65, 128), (129, 512), (513, 1 << 30))])
+
+# per-CU timeline of the exact kernel: HW_ID bits cu_id[11:8] sh_id[12] se_id[15:13], XCC_ID in the high half
+hw = s[:, 7]
+cu = ((hw >> 8) & 0xff) | ((hw >> 16) << 8)
+t0 = s[:, 5].astype(np.int64); t1 = s[:, 6].astype(np.int64)
+t1 = np.where(t1 < t0, t1 + (1 << 32), t1)
+spans = []; busy = []; conc = []; nwg = []
+for c in sorted(set(cu.tolist())):
+    m = cu == c
+    ev = sorted([(a, 1) for a in t0[m]] + [(b, -1) for b in t1[m]])
+    lvl = 0; last = ev[0][0]; b = 0; area = 0
+    for t, d in ev:
+        if lvl > 0: b += t - last
+        area += lvl * (t - last)
+        last = t; lvl += d
+    sp = ev[-1][0] - ev[0][0]
+    spans.append(sp); busy.append(b / sp); conc.append(area / max(b, 1)); nwg.append(int(m.sum()))
+spans = np.array(spans)
+print("CUs seen: %d | per-CU span (first WG start .. last WG end), cycles: mean %.0f max %.0f min %.0f" % (len(spans), spans.mean(), spans.max(), spans.min()))
+print("WG residency mean %.0f | busy fraction of the CU's own span: mean %.3f min %.3f | concurrent WGs while busy: mean %.2f" % ((t1 - t0).mean(), np.mean(busy), np.min(busy), np.mean(conc)))
+print("WGs per CU: min %d max %d mean %.1f" % (min(nwg), max(nwg), np.mean(nwg)))
+xcc = np.array(sorted(set(cu.tolist()))) >> 8
+for x in sorted(set(xcc.tolist())):
+    mm = xcc == x
+    print("  XCC %d: CUs %d, WGs %d, span mean %.0f max %.0f" % (x, mm.sum(), np.array(nwg)[mm].sum(), spans[mm].mean(), spans[mm].max()))
+
+est = s[:, 8]; n1 = s[:, 1]
+print("est >= 1024: %d CTUs; of the %d CTUs with n1 > 512, est >= 1024 for %d; est quantiles (10/50/90/99): %s" % (
+    (est >= 1024).sum(), (n1 > 512).sum(), ((n1 > 512) & (est >= 1024)).sum(), np.percentile(est, [10, 50, 90, 99]).tolist()))
+heavy = n1 > 512
+print("heavy CTUs: start time relative to the CU's first start (cycles), quantiles 50/90/100:",
+      np.percentile([t0[i] - t0[cu == cu[i]].min() for i in np.nonzero(heavy)[0]], [50, 90, 100]).tolist())
+miss = np.nonzero((n1 > 512) & (est < 1024))[0]
+print("missed heavy CTUs (n1, est):", [(int(n1[i]), int(est[i])) for i in miss])
+for lo, hi in ((0, 450), (450, 500), (500, 600), (600, 768), (768, 1024), (1024, 2048), (2048, 1 << 30)):
+    m = (est >= lo) & (est < hi)
+    if m.any():
+        print("est [%d,%d): %d CTUs, n1 mean %.0f max %d, residency mean %.0f max %d" % (lo, hi, m.sum(), n1[m].mean(), n1[m].max(), (t1 - t0)[m].mean(), (t1 - t0)[m].max()))

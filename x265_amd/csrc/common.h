@@ -18,6 +18,7 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? X265AMD_OK : X265
 // set by x265amd_init(); entry points refuse to launch before it
 bool initialised();
 int lds_limit_bytes();
+int cu_count();
 
 inline int ilog2(int n)
 {

@@ -118,25 +118,32 @@ constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or alread
 __device__ __forceinline__ uint32_t lb_store(uint32_t lb) { return lb >> 4; }
 
 struct SeaHdr {  // per (plane, CTU)
-    uint32_t n0;  // groups in the first batch
-    uint32_t pad[3];
+    uint32_t n0;        // groups in the first batch (<= kFirst)
+    uint32_t rest_min;  // smallest stored bound among the groups NOT in it (kNone: none left)
+    uint32_t est;       // groups with a bound within 2x of the first batch's threshold (work estimate)
+    uint32_t pad;
 };
+constexpr int kFirst = 256;   // first batch: two rounds of 128 groups
+constexpr int kClasses = 4;   // launch-order classes of the work estimate, heaviest first
+__device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est >= 1024 ? 1 : est >= 600 ? 2 : 3; }
 
 // ---------------------------------------------------------------------------------------------
 // Kernel 1: bounds.  No window, 9 KB of LDS => high occupancy hides the box-sum loads.
 //   out: gl[plane][ctu][max_groups] u16 bound per group (kNone where scheduled / illegal),
-//        list0[plane][ctu][..] the first batch (lowest histogram bins until >= 256 groups), hdr.n0
+//        list0[plane][ctu][..] the first batch (the kFirst groups of the lowest histogram bins), hdr
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
                                                                  const uint16_t *__restrict__ bbuf,
                                                                  uint16_t *__restrict__ gl, uint16_t *__restrict__ list0,
-                                                                 SeaHdr *__restrict__ hdr, const MeGeom g, int max_groups)
+                                                                 SeaHdr *__restrict__ hdr, uint32_t *__restrict__ order,
+                                                                 uint32_t *__restrict__ ctrl, const MeGeom g, int max_groups)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint16_t *glb = reinterpret_cast<uint16_t *>(smem);  // [ndy][ngx]
     __shared__ uint32_t hist[kBins];
     __shared__ uint32_t csum[16];
-    __shared__ int list_n, pick_bin;
+    __shared__ int list_n, eq_n, pick_bin, below_n, est_n;
+    __shared__ uint32_t rest_lb;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int ctx = blockIdx.x, cty = blockIdx.y;
@@ -148,7 +155,11 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
     const int64_t ctu_id = ((int64_t)blockIdx.z * g.ctus_y + cty) * g.ctus_x + ctx;
 
     if (tid < kBins) hist[tid] = 0;
-    if (tid == 0) list_n = 0;
+    if (tid == 0) {
+        list_n = 0;
+        eq_n = 0;
+        rest_lb = kNone;
+    }
     // ---- the CTU's sub-block sums: 16 lanes per sub-block, one 16-pixel row each ----
     if (tid < 256) {
         const int b = tid >> 4, rrow = tid & 15;
@@ -227,7 +238,9 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
     }
     __syncthreads();
 
-    // ---- first batch: the lowest bins until at least 256 groups ----
+    // ---- first batch: the kFirst groups of the lowest bins.  pick_bin = the bin in which the running
+    //      count reaches kFirst; below_n = groups in the bins under it (all taken), the rest of the
+    //      quota comes from pick_bin itself, whichever of its groups the scan reaches first ----
     if (tid < 64) {
         uint32_t c0 = hist[tid], c1 = (tid + 64 < kBins) ? hist[tid + 64] : 0u;
         uint32_t s0 = c0;
@@ -244,43 +257,92 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
             if (lane >= o) s1 += t;
         }
         s1 += tot0;
-        const unsigned long long m0 = __ballot(s0 >= 256u), m1 = __ballot(s1 >= 256u && tid + 64 < kBins);
-        if (tid == 0) pick_bin = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : kBins);
+        const unsigned long long m0 = __ballot(s0 >= (uint32_t)kFirst), m1 = __ballot(s1 >= (uint32_t)kFirst && tid + 64 < kBins);
+        const int pbv = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : kBins);
+        const uint32_t incl = pbv < 64 ? __shfl(s0, pbv & 63) : __shfl(s1, pbv & 63);  // count through pick_bin
+        const uint32_t own = pbv < 64 ? __shfl(c0, pbv & 63) : __shfl(c1, pbv & 63);
+        // work estimate for the launch order of kernel 2: groups whose bound is within 2x (four
+        // quarter-octave bins) of the first batch's threshold -- nearly all of them on content the
+        // bound cannot separate, a few hundred otherwise
+        const int eb = pbv + 4 < kBins - 1 ? pbv + 4 : kBins - 1;
+        const uint32_t est = eb < 64 ? __shfl(s0, eb & 63) : __shfl(s1, eb & 63);
+        if (tid == 0) {
+            pick_bin = pbv;
+            below_n = pbv < kBins ? (int)(incl - own) : 0;
+            est_n = (int)est;
+        }
     }
     __syncthreads();
     const int pb = pick_bin;
+    const int nbelow = below_n;            // list0[0 .. nbelow) = bins < pb
+    const int quota = kFirst - nbelow;     // list0[nbelow .. nbelow + min(quota, |bin pb|)) = bin pb
 
-    // ---- write the bounds out; groups of the first batch go to list0 (scan order) and are marked ----
+    // ---- write the bounds out; groups of the first batch go to list0 (scan order within a wave) and
+    //      are marked; the smallest bound left over goes to the header ----
     uint16_t *glo = gl + ctu_id * max_groups;
     uint16_t *lo = list0 + ctu_id * max_groups;
+    uint32_t rest_min = kNone;
     for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
         const int gi = g0 + tid;
         const uint32_t v = gi < L.ngroups ? (uint32_t)glb[gi] : kNone;
-        const bool take = v != kNone && lb_bin(v) <= pb;
-        const unsigned long long tm = __ballot(take);
-        int wbase = 0;
-        if (lane == 0 && tm) wbase = atomicAdd(&list_n, (int)__popcll(tm));
-        wbase = __shfl(wbase, 0);
+        const int bin = v != kNone ? lb_bin(v) : kBins + 1;
+        const bool lo_take = bin < pb || (pb == kBins && bin < kBins);
+        const bool eq = bin == pb && pb < kBins;
+        const unsigned long long tl = __ballot(lo_take), te = __ballot(eq);
+        int wl = 0, we = 0;
+        if (lane == 0) {
+            if (tl) wl = atomicAdd(&list_n, (int)__popcll(tl));
+            if (te) we = atomicAdd(&eq_n, (int)__popcll(te));
+        }
+        wl = __shfl(wl, 0);
+        we = __shfl(we, 0);
+        bool take = lo_take;
+        int slot = wl + (int)__popcll(tl & ((1ull << lane) - 1ull));
+        if (eq) {
+            const int r = we + (int)__popcll(te & ((1ull << lane) - 1ull));
+            take = r < quota;
+            slot = nbelow + r;
+        }
         if (take) {
             const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
-            lo[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)((dyi << 7) | gx);
+            lo[slot] = (uint16_t)((dyi << 7) | gx);
+        } else if (v != kNone) {
+            rest_min = min(rest_min, v);
         }
         if (gi < L.ngroups) glo[gi] = take ? (uint16_t)kNone : (uint16_t)v;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rest_min = min(rest_min, (uint32_t)__shfl_xor((int)rest_min, o));
+    if (lane == 0 && rest_min != kNone) atomicMin(&rest_lb, rest_min);
     __syncthreads();
-    if (tid == 0) hdr[ctu_id].n0 = (uint32_t)list_n;
+    if (tid == 0) {
+        SeaHdr h;
+        h.n0 = (uint32_t)(pb == kBins ? list_n : nbelow + min(quota, eq_n));
+        h.rest_min = rest_lb;  // kNone: nothing left over
+        h.est = (uint32_t)est_n;
+        h.pad = 0;
+        hdr[ctu_id] = h;
+        // launch order of kernel 2: longest first, in kClasses classes of the estimate (a queue each)
+        const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+        const int cls = sea_class(est_n);
+        order[(size_t)cls * total + atomicAdd(&ctrl[cls], 1u)] = (uint32_t)ctu_id;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// Kernel 2: exact SADs.  Window in LDS; first batch from list0, then everything whose bound is
-// still <= best (one scan of the u16 bounds), 128 groups at a time: a lane = one group (4 dx at one
-// dy) x 16 rows, 8 waves = 2 sets of 64 groups x 4 row quarters, partial sums merged through LDS.
+// Kernel 2: exact SADs.  Window in LDS.  Round = 128 groups: a lane = one group (4 dx at one dy) x 16
+// rows, 8 waves = 2 sets of 64 groups x 4 row quarters; the quarter-0 wave of each set merges the
+// partial sums (double-buffered through LDS: one barrier per round).  The first batch (<= 2 rounds)
+// comes from list0 with its entries already in registers when the window has landed; a second pass is
+// needed only if a group outside it has a bound <= the best SAD found (hdr.rest_min tells without a scan).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t *__restrict__ cur_base,
                                                                    const uint8_t *__restrict__ ref_base,
                                                                    const uint16_t *__restrict__ gl,
                                                                    const uint16_t *__restrict__ list0,
                                                                    const SeaHdr *__restrict__ hdr,
+                                                                   const uint32_t *__restrict__ order,
+                                                                   uint32_t *__restrict__ ctrl, int total,
                                                                    x265amd_mv *__restrict__ out, const MeGeom g,
                                                                    int max_groups, int win_dwords,
                                                                    uint32_t *__restrict__ stats)
@@ -288,23 +350,72 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *win = smem;                                                     // [win_rows][pitch] reference window
     uint16_t *list = reinterpret_cast<uint16_t *>(smem + win_dwords);         // second-pass schedule
-    __shared__ __attribute__((aligned(16))) uint32_t part[8 * 64 * 4];        // partial SADs: [wave][lane][4 dx]
+    __shared__ __attribute__((aligned(16))) uint32_t part[2][8 * 64 * 4];     // partial SADs: [round & 1][wave][lane][4 dx]
     __shared__ unsigned long long best_key;
-    __shared__ int list_n;
+    __shared__ int list_n, next_ctu;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: keeps the current rows in SGPRs
-    const int ctx = blockIdx.x, cty = blockIdx.y;
-    const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
-    const int cx = ctx * 64, cy = cty * 64;
+    const int set = wave >> 2, qtr = wave & 3;
     const int R = g.range;
+    const int span = 2 * R + 1;
+    const int cstr = g.stride >> 2;
+    const int per_plane = g.ctus_x * g.ctus_y;
+    int round = 0;
+
+    // Persistent workgroups: each takes the next CTU of the launch order (ctrl[2] counts them out) until
+    // none is left -- every wave reaches that exit.  The index of the NEXT CTU is fetched while this
+    // one is being searched.
+    uint32_t cls_end[kClasses];  // running ends of the class queues in hand-out order (final: kernel 1 is done)
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int c = 0; c < kClasses; c++) {
+            acc += ctrl[c];
+            cls_end[c] = acc;
+        }
+    }
+    auto item_ctu = [&](int it) -> uint32_t {  // it < total
+        int c = 0;
+        uint32_t beg = 0;
+#pragma unroll
+        for (int k = 0; k < kClasses - 1; k++)
+            if ((uint32_t)it >= cls_end[k]) {
+                c = k + 1;
+                beg = cls_end[k];
+            }
+        return order[(size_t)c * total + ((uint32_t)it - beg)];
+    };
+    if (tid == 0) {
+        const int it = (int)atomicAdd(&ctrl[kClasses], 1u);
+        next_ctu = it < total ? (int)item_ctu(it) : -1;
+    }
+    __syncthreads();
+    int ctu_now = next_ctu;
+  while (ctu_now >= 0) {
+    int it_next = 0;
+    uint32_t ctu_next_v = 0;
+    if (tid == 0) {
+        it_next = (int)atomicAdd(&ctrl[kClasses], 1u);
+        ctu_next_v = item_ctu(it_next < total ? it_next : 0);
+    }
+    const int64_t ctu_id = ctu_now;
+    const int plane = ctu_now / per_plane, cin = ctu_now - plane * per_plane;
+    const int cty = cin / g.ctus_x, ctx = cin - cty * g.ctus_x;
+    const int f = plane / g.nrefs, rr = plane - f * g.nrefs;
+    const int cx = ctx * 64, cy = cty * 64;
     const SeaLayout L = sea_layout(g.width, g.height, R, cx, cy);
     const uint8_t *cur = cur_base + f * g.cur_fs;
     const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
-    const int span = 2 * R + 1;
-    const int64_t ctu_id = ((int64_t)blockIdx.z * g.ctus_y + cty) * g.ctus_x + ctx;
     const uint16_t *glo = gl + ctu_id * max_groups;
     const uint16_t *l0 = list0 + ctu_id * max_groups;
+
+    // the first batch's entries of this lane (rounds 0 and 1) and the header: in flight with the window
+    const long long t_begin = stats ? clock64() : 0;
+    const int e_hi = max_groups - 1;
+    int ent0 = (int)l0[min(set * 64 + lane, e_hi)];
+    int ent1 = (int)l0[min(128 + set * 64 + lane, e_hi)];
+    const SeaHdr h = hdr[ctu_id];
 
     // ---- stage the reference window: a wave per row, a lane per dword, 13 rows in flight ----
     constexpr int kWinInFlight = 13;
@@ -333,60 +444,26 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
         best_key = ~0ull;
         list_n = 0;
     }
-    const int n0 = (int)hdr[ctu_id].n0;
+    const int n0 = __builtin_amdgcn_readfirstlane((int)h.n0);
+    const uint32_t rest_min = __builtin_amdgcn_readfirstlane(h.rest_min);
     __syncthreads();
 
+    const long long t_staged = stats ? clock64() : 0;
     const uint32_t *__restrict__ cbase = reinterpret_cast<const uint32_t *>(cur + (int64_t)cy * g.stride + cx);
-    const int cstr = g.stride >> 2;
-    const int set = wave >> 2, qtr = wave & 3;
-    int n1 = 0;
 
-    for (int pass = 0; pass < 2; pass++) {
-        int n = n0;
-        if (pass == 1) {
-            // ---- everything not yet scheduled whose bound is <= best: sweep 1 counts the wave's takers,
-            //      ONE LDS atomic reserves their slots, sweep 2 fills them in scan order ----
-            const uint32_t best_sad = (uint32_t)(best_key >> 32);
-            int wcount = 0;
-            for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
-                const int gi = g0 + tid;
-                const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
-                wcount += (int)__popcll(__ballot(v != kNone && (v << 4) <= best_sad));
-            }
-            int wbase = 0;
-            if (lane == 0 && wcount) wbase = atomicAdd(&list_n, wcount);
-            wbase = __builtin_amdgcn_readfirstlane(wbase);
-            if (wcount) {
-                for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
-                    const int gi = g0 + tid;
-                    const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
-                    const bool take = v != kNone && (v << 4) <= best_sad;
-                    const unsigned long long tm = __ballot(take);
-                    if (take) {
-                        const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
-                        list[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)((dyi << 7) | gx);
-                    }
-                    wbase += (int)__popcll(tm);
-                }
-            }
-            __syncthreads();
-            n = list_n;
-            n1 = n;
-        }
-        for (int base = 0; base < n; base += 128) {
-            {
-                const int li = base + set * 64 + lane;
-                const bool have = li < n;
-                const int ent = pass == 0 ? (int)l0[have ? li : n - 1] : (int)list[have ? li : n - 1];
-                const int dyi = ent >> 7, gx = ent & 127;
-                if (__ballot(have) != 0ull) {  // wave-uniform
-                    const uint32_t *wrow = win + (dyi + 16 * qtr) * L.pitch + gx;
-                    const uint32_t *crow = cbase + (16 * qtr) * cstr;
-                    uint32_t acc32[4] = {0u, 0u, 0u, 0u};
-                    // two-row software pipeline: the loads of row r+1 (17 window dwords by ds_read2,
-                    // 16 current dwords by s_load) are in flight while row r's sixteen qsads issue
-                    uint32_t dA[17], dB[17], SA[16], SB[16];
-                    uint64_t acc16 = 0;
+    // one round for this wave: `ent` = the lane's group (valid where `have`)
+    auto run_round = [&](int ent, bool have) {
+        ent = have ? ent : 0;
+        const int dyi = ent >> 7, gx = ent & 127;
+        uint32_t *pbuf = part[round & 1];
+        if (__ballot(have) != 0ull) {  // wave-uniform
+            const uint32_t *wrow = win + (dyi + 16 * qtr) * L.pitch + gx;
+            const uint32_t *crow = cbase + (16 * qtr) * cstr;
+            uint32_t acc32[4] = {0u, 0u, 0u, 0u};
+            // two-row software pipeline: the loads of row r+1 (17 window dwords by ds_read2,
+            // 16 current dwords by s_load) are in flight while row r's sixteen qsads issue
+            uint32_t dA[17], dB[17], SA[16], SB[16];
+            uint64_t acc16 = 0;
 #define SEA_LOAD(r, d, S)                                                   \
     {                                                                       \
         const uint32_t *p_ = wrow + (r) * L.pitch;                          \
@@ -396,68 +473,102 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
 #define SEA_ROW(d, S)                                                                                   \
     _Pragma("unroll") for (int k = 0; k < 16; k++)                                                     \
         acc16 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], S[k], acc16);
-                    SEA_LOAD(0, dA, SA)
+            SEA_LOAD(0, dA, SA)
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): row r has landed ...
-                        SEA_LOAD(r + 1, dB, SB)              // ... row r+1 goes out before row r's qsads
-                        __builtin_amdgcn_sched_barrier(0);
-                        SEA_ROW(dA, SA)
-                        __builtin_amdgcn_sched_barrier(0);
-                        __builtin_amdgcn_s_waitcnt(0xc07f);
-                        if (r + 2 < 16) SEA_LOAD(r + 2, dA, SA)
-                        __builtin_amdgcn_sched_barrier(0);
-                        SEA_ROW(dB, SB)
-                        __builtin_amdgcn_sched_barrier(0);
-                        if ((r & 3) == 2) {  // every 4 rows: 64 qsads * 1020 < 2^16
+            for (int r = 0; r < 16; r += 2) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): row r has landed ...
+                SEA_LOAD(r + 1, dB, SB)              // ... row r+1 goes out before row r's qsads
+                __builtin_amdgcn_sched_barrier(0);
+                SEA_ROW(dA, SA)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (r + 2 < 16) SEA_LOAD(r + 2, dA, SA)
+                __builtin_amdgcn_sched_barrier(0);
+                SEA_ROW(dB, SB)
+                __builtin_amdgcn_sched_barrier(0);
+                if ((r & 3) == 2) {  // every 4 rows: 64 qsads * 1020 < 2^16
 #pragma unroll
-                            for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
-                            acc16 = 0;
-                        }
-                    }
+                    for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
+                    acc16 = 0;
+                }
+            }
 #undef SEA_LOAD
 #undef SEA_ROW
-                    *reinterpret_cast<uint4 *>(&part[(wave * 64 + lane) * 4]) = make_uint4(acc32[0], acc32[1], acc32[2], acc32[3]);
+            *reinterpret_cast<uint4 *>(&pbuf[(wave * 64 + lane) * 4]) = make_uint4(acc32[0], acc32[1], acc32[2], acc32[3]);
+        }
+        __syncthreads();
+        if (qtr == 0 && __ballot(have) != 0ull) {  // the set's quarter-0 wave adds the four quarters up
+            unsigned long long k = ~0ull;
+            if (have) {
+                const int dy = L.dylo + dyi;
+                uint4 s = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) {
+                    const uint4 t = *reinterpret_cast<const uint4 *>(&pbuf[((wave + q4) * 64 + lane) * 4]);
+                    s.x += t.x;
+                    s.y += t.y;
+                    s.z += t.z;
+                    s.w += t.w;
+                }
+                const uint32_t sad[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int dx = L.wx0 - cx + 4 * gx + q;
+                    if (dx >= L.dxlo && dx <= L.dxhi) {
+                        const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
+                        k = key < k ? key : k;
+                    }
                 }
             }
-            __syncthreads();
-            if (tid < 128) {  // waves 0 and 1 combine the four row quarters of set 0 and set 1
-                const int li = base + tid;
-                const bool have = li < n;
-                if (__ballot(have) != 0ull) {
-                    unsigned long long k = ~0ull;
-                    if (have) {
-                        const int ent = pass == 0 ? (int)l0[li] : (int)list[li];
-                        const int dyi = ent >> 7, gx = ent & 127;
-                        const int dy = L.dylo + dyi;
-                        uint4 s = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; q4++) {
-                            const uint4 t = *reinterpret_cast<const uint4 *>(&part[((wave * 4 + q4) * 64 + lane) * 4]);
-                            s.x += t.x;
-                            s.y += t.y;
-                            s.z += t.z;
-                            s.w += t.w;
-                        }
-                        const uint32_t sad[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int dx = L.wx0 - cx + 4 * gx + q;
-                            if (dx >= L.dxlo && dx <= L.dxhi) {
-                                const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
-                                k = key < k ? key : k;
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const unsigned long long other = __shfl_xor(k, o);
-                        k = other < k ? other : k;
-                    }
-                    if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
-                }
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(k, o);
+                k = other < k ? other : k;
             }
-            __syncthreads();  // part[] is reused; best_key is read after the pass
+            if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
+        }
+        round++;  // the next round writes the other half of part[]: no second barrier
+    };
+
+    // ---- pass 0: the first batch ----
+    run_round(ent0, set * 64 + lane < n0);
+    if (n0 > 128) run_round(ent1, 128 + set * 64 + lane < n0);
+    __syncthreads();
+
+    const long long t_pass0 = stats ? clock64() : 0;
+    // ---- pass 1, only if some group left over has a bound <= the best SAD so far ----
+    int n1 = 0;
+    const uint32_t best_sad = (uint32_t)(best_key >> 32);
+    if (rest_min != kNone && (rest_min << 4) <= best_sad) {
+        // sweep 1 counts the wave's takers, ONE LDS atomic reserves their slots, sweep 2 fills them in scan order
+        int wcount = 0;
+        for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
+            const int gi = g0 + tid;
+            const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
+            wcount += (int)__popcll(__ballot(v != kNone && (v << 4) <= best_sad));
+        }
+        int wbase = 0;
+        if (lane == 0 && wcount) wbase = atomicAdd(&list_n, wcount);
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (wcount) {
+            for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
+                const int gi = g0 + tid;
+                const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
+                const bool take = v != kNone && (v << 4) <= best_sad;
+                const unsigned long long tm = __ballot(take);
+                if (take) {
+                    const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+                    list[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)((dyi << 7) | gx);
+                }
+                wbase += (int)__popcll(tm);
+            }
+        }
+        __syncthreads();
+        n1 = list_n;
+        for (int base = 0; base < n1; base += 128) {
+            const int li = base + set * 64 + lane;
+            const bool have = li < n1;
+            run_round((int)list[have ? li : 0], have);
         }
         __syncthreads();
     }
@@ -468,12 +579,25 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
         mv.mvx = (int16_t)(c % span - R);
         mv.mvy = (int16_t)(c / span - R);
         mv.sad = (uint32_t)(best >> 32);
-        out[((int64_t)f * g.nrefs + rr) * g.ctus_x * g.ctus_y + cty * g.ctus_x + ctx] = mv;
+        out[ctu_id] = mv;
         if (stats) {
-            stats[8 * ctu_id + 0] = (uint32_t)n0;
-            stats[8 * ctu_id + 1] = (uint32_t)n1;
+            stats[16 * ctu_id + 0] = (uint32_t)n0;
+            stats[16 * ctu_id + 1] = (uint32_t)n1;
+            stats[16 * ctu_id + 2] = (uint32_t)(t_staged - t_begin);  // cycles: window staging
+            stats[16 * ctu_id + 3] = (uint32_t)(t_pass0 - t_staged);  //         first batch
+            const long long t_end = clock64();
+            stats[16 * ctu_id + 4] = (uint32_t)(t_end - t_pass0);     //         second pass
+            stats[16 * ctu_id + 5] = (uint32_t)t_begin;               // absolute, low 32 bits
+            stats[16 * ctu_id + 6] = (uint32_t)t_end;
+            stats[16 * ctu_id + 8] = h.est;
+            stats[16 * ctu_id + 9] = (uint32_t)blockIdx.x;
+            stats[16 * ctu_id + 7] = (__builtin_amdgcn_s_getreg(63492) & 0xffffu) | (__builtin_amdgcn_s_getreg(6164) << 16);  // HW_ID | XCC_ID
         }
+        next_ctu = it_next < total ? (int)ctu_next_v : -1;
     }
+    __syncthreads();  // the window and part[] are free again; next_ctu is visible
+    ctu_now = next_ctu;
+  }
 }
 
 }  // namespace x265amd
@@ -481,8 +605,28 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
 using namespace x265amd;
 
 static uint32_t *g_me_stats = nullptr;
-// debugging aid (not part of the ABI): 8 u32 per workgroup; [0] / [1] = groups evaluated in pass 0 / 1
+// debugging aid (not part of the ABI): 16 u32 per CTU; [0] / [1] = groups evaluated in pass 0 / 1
 extern "C" void x265amd_debug_set_me_stats(uint32_t *d_stats) { g_me_stats = d_stats; }
+
+// debugging aid (not part of the ABI): per-kernel HIP-event timing of the last _sea call on its own stream.
+// bench.py uses it so that the roofline line can name each kernel's duration without a profiler attached.
+static bool g_me_timing = false;
+static hipEvent_t g_me_ev[5];
+extern "C" int x265amd_debug_me_timing(int enable)
+{
+    if (enable && !g_me_ev[0])
+        for (auto &e : g_me_ev) X265AMD_HIP(hipEventCreate(&e));
+    g_me_timing = enable != 0;
+    return X265AMD_OK;
+}
+// ms of box16_h, box16_v, sea_bounds_kernel, sea_exact_kernel of the last timed call (waits for it)
+extern "C" int x265amd_debug_me_last_ms(float *out4)
+{
+    if (!g_me_ev[0] || !out4) return X265AMD_ERR_ARG;
+    X265AMD_HIP(hipEventSynchronize(g_me_ev[4]));
+    for (int i = 0; i < 4; i++) X265AMD_HIP(hipEventElapsedTime(&out4[i], g_me_ev[i], g_me_ev[i + 1]));
+    return X265AMD_OK;
+}
 
 // largest per-CTU geometry of a picture: rows / pitch of the window, groups per row, rows of candidates
 static void sea_extents(int width, int height, int range, int &max_rows, int &max_pitch, int &max_ngx, int &max_ndy)
@@ -511,7 +655,9 @@ extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, i
     const size_t per_ctu = (size_t)max_ngx * max_ndy;
     return align256(2 * sizeof(uint16_t) * width * height * planes)        // H16 + B16 per (frame, ref) plane
            + 2 * align256(sizeof(uint16_t) * per_ctu * nctu * planes)      // bounds + first-batch list per CTU
-           + align256(sizeof(SeaHdr) * nctu * planes);
+           + align256(sizeof(SeaHdr) * nctu * planes)
+           + align256(sizeof(uint32_t) * kClasses * nctu * planes)         // launch-order queues of the exact kernel
+           + 256;                                                          // their counters
 }
 
 extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
@@ -539,7 +685,7 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     const int win_dwords = max_rows * max_pitch;
     size_t lds_exact = (size_t)win_dwords * 4 + (((size_t)max_groups * 2 + 15) & ~(size_t)15);
     if (const char *pad = getenv("X265AMD_SEA_LDS_PAD")) lds_exact += (size_t)atoi(pad);  // occupancy experiments only
-    if (lds_exact + 9216 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;  // + the kernel's static LDS
+    if (lds_exact + 17408 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;  // + the kernel's static LDS
     const size_t lds_bounds = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
 
     const size_t nctu = (size_t)(width / 64) * (height / 64);
@@ -552,12 +698,22 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     uint16_t *list0 = (uint16_t *)ws;
     ws += align256(sizeof(uint16_t) * (size_t)max_groups * nctu * (size_t)nplanes);
     SeaHdr *hdr = (SeaHdr *)ws;
+    ws += align256(sizeof(SeaHdr) * nctu * (size_t)nplanes);
+    uint32_t *order = (uint32_t *)ws;
+    ws += align256(sizeof(uint32_t) * kClasses * nctu * (size_t)nplanes);
+    uint32_t *ctrl = (uint32_t *)ws;  // [0..kClasses) queue lengths, [kClasses] next item to hand out
+    if ((int64_t)nctu * nplanes > 0x7fffffff) return X265AMD_ERR_ARG;
+    const int total = (int)(nctu * (size_t)nplanes);
 
     hipStream_t st = (hipStream_t)stream;
+    const bool timing = g_me_timing;
+    if (timing) (void)hipEventRecord(g_me_ev[0], st);
     hipLaunchKernelGGL(box16_h, dim3((width / 4 + 255) / 256, height, (unsigned)nplanes), dim3(256), 0, st, d_ref, hbuf,
                        width, height, stride, nrefs, ref_frame_stride, ref_ref_stride);
+    if (timing) (void)hipEventRecord(g_me_ev[1], st);
     hipLaunchKernelGGL(box16_v, dim3((width / 2 + 255) / 256, (height + kBoxVRows - 1) / kBoxVRows, (unsigned)nplanes),
                        dim3(256), 0, st, hbuf, bbuf, width, height);
+    if (timing) (void)hipEventRecord(g_me_ev[2], st);
     MeGeom g;
     g.width = width;
     g.height = height;
@@ -570,11 +726,19 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     g.ref_fs = ref_frame_stride;
     g.ref_rs = ref_ref_stride;
     const dim3 grid(g.ctus_x, g.ctus_y, (unsigned)nplanes);
-    hipLaunchKernelGGL(sea_bounds_kernel, grid, dim3(kSeaThreads), lds_bounds, st, d_cur, bbuf, gl, list0, hdr, g,
-                       max_groups);
+    X265AMD_HIP(hipMemsetAsync(ctrl, 0, 4 * (kClasses + 1), st));
+    hipLaunchKernelGGL(sea_bounds_kernel, grid, dim3(kSeaThreads), lds_bounds, st, d_cur, bbuf, gl, list0, hdr, order,
+                       ctrl, g, max_groups);
+    if (timing) (void)hipEventRecord(g_me_ev[3], st);
     X265AMD_HIP(hipFuncSetAttribute((const void *)sea_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_exact));
-    hipLaunchKernelGGL(sea_exact_kernel, grid, dim3(kSeaThreads), lds_exact, st, d_cur, d_ref, gl, list0, hdr, d_out, g,
-                       max_groups, win_dwords, g_me_stats);
+    // as many workgroups as the chip holds at once (LDS- and register-bound), each looping over CTUs
+    int per_cu = 0;
+    X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)sea_exact_kernel, kSeaThreads, lds_exact));
+    if (per_cu < 1) return X265AMD_ERR_LDS;
+    const int resident = per_cu * cu_count();
+    hipLaunchKernelGGL(sea_exact_kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(kSeaThreads), lds_exact,
+                       st, d_cur, d_ref, gl, list0, hdr, order, ctrl, total, d_out, g, max_groups, win_dwords, g_me_stats);
+    if (timing) (void)hipEventRecord(g_me_ev[4], st);
     return hip_status(hipGetLastError());
 }

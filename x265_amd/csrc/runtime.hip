@@ -10,9 +10,11 @@ namespace x265amd {
 static std::mutex g_mu;
 static bool g_init = false;
 static int g_lds_limit = 64 * 1024;
+static int g_cu_count = 256;
 
 bool initialised() { return g_init; }
 int lds_limit_bytes() { return g_lds_limit; }
+int cu_count() { return g_cu_count; }
 
 }  // namespace x265amd
 
@@ -33,6 +35,7 @@ extern "C" int x265amd_init(int device)
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
         g_lds_limit = lds;
+    if (prop.multiProcessorCount > 0) g_cu_count = prop.multiProcessorCount;
     g_init = true;
     return X265AMD_OK;
 }
