@@ -22,7 +22,10 @@ lib.x265amd_debug_set_me_stats(None)
 s = stats.cpu().numpy().astype(np.int64).reshape(-1, 16)
 nctu_all = s.shape[0]
 names = ["n_pass0", "n_pass1", "cyc_stage", "cyc_pass0", "cyc_pass1"]
+bnames = {10: "b_cyc_csum", 11: "b_cyc_bounds", 12: "b_cyc_scan", 13: "b_cyc_write"}
 for i, n in enumerate(names):
+    print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
+for i, n in bnames.items():
     print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
 interior = [i for i in range(nctu_all) if 2 <= (i % nctu) % 30 <= 27 and 2 <= (i % nctu) // 30 <= 14]
 print("interior CTUs:", {n: float(s[interior, i].mean()) for i, n in enumerate(names)})

@@ -54,28 +54,37 @@ __global__ __launch_bounds__(256) void box16_h(const uint8_t *__restrict__ ref_b
     *reinterpret_cast<uint2 *>(hbuf + ((int64_t)pl * height + y) * width + 4 * xq) = o;
 }
 
-// vertical: B16[y][x] = sum_{k<16} H16[y+k][x]; a thread owns 2 columns (packed u16) and a run of rows
+// vertical: B16[y][x] = sum_{k<16} H16[y+k][x], written as PAIRS P[y][x] = B16[y][x] | B16[y][x+16] << 16:
+// the two sub-blocks of one candidate that sit side by side share a dword, so that one v_sad_u16
+// adds both |differences| to the candidate's bound.  A thread owns columns 2xp, 2xp+1 and their
+// partners 16 to the right (packed u16 pairs) and a run of rows.
 constexpr int kBoxVRows = 32;
-__global__ __launch_bounds__(256) void box16_v(const uint16_t *__restrict__ hbuf, uint16_t *__restrict__ bbuf, int width,
+__global__ __launch_bounds__(256) void box16_v(const uint16_t *__restrict__ hbuf, uint32_t *__restrict__ pbuf, int width,
                                                int height)
 {
     const int xp = blockIdx.x * 256 + threadIdx.x;  // pair of columns
     const int y0 = blockIdx.y * kBoxVRows;
     const int pl = blockIdx.z;
     if (2 * xp >= width) return;
-    const uint32_t *h = reinterpret_cast<const uint32_t *>(hbuf + (int64_t)pl * height * width) + xp;
-    uint32_t *b = reinterpret_cast<uint32_t *>(bbuf + (int64_t)pl * height * width) + xp;
     const int wp = width >> 1;
+    const bool far_ok = xp + 8 < wp;  // partner columns inside the plane (else no legal candidate uses them)
+    const uint32_t *hn = reinterpret_cast<const uint32_t *>(hbuf + (int64_t)pl * height * width) + xp;
+    const uint32_t *hf = hn + (far_ok ? 8 : 0);
+    uint2 *p = reinterpret_cast<uint2 *>(pbuf + (int64_t)pl * height * width) + xp;
     if (y0 + 16 > height) return;
-    uint32_t acc = 0;  // two u16 sums; 16 * 4080 < 2^16, so the packed add never carries across
+    uint32_t an = 0, af = 0;  // two u16 sums each; 16 * 4080 < 2^16, so the packed adds never carry across
 #pragma unroll
-    for (int k = 0; k < 16; k++) acc += h[(int64_t)(y0 + k) * wp];
-    b[(int64_t)y0 * wp] = acc;
+    for (int k = 0; k < 16; k++) {
+        an += hn[(int64_t)(y0 + k) * wp];
+        af += hf[(int64_t)(y0 + k) * wp];
+    }
+    p[(int64_t)y0 * wp] = make_uint2((an & 0xffffu) | (af << 16), (an >> 16) | (af & 0xffff0000u));
     for (int y = y0 + 1; y < y0 + kBoxVRows && y + 16 <= height; y++) {
         // packed u16 pair: take the old row out first (each half contains it: no borrow), then the
         // new row in (each half <= 16 * 4080 < 2^16: no carry)
-        acc = (acc - h[(int64_t)(y - 1) * wp]) + h[(int64_t)(y + 15) * wp];
-        b[(int64_t)y * wp] = acc;
+        an = (an - hn[(int64_t)(y - 1) * wp]) + hn[(int64_t)(y + 15) * wp];
+        af = (af - hf[(int64_t)(y - 1) * wp]) + hf[(int64_t)(y + 15) * wp];
+        p[(int64_t)y * wp] = make_uint2((an & 0xffffu) | (af << 16), (an >> 16) | (af & 0xffff0000u));
     }
 }
 
@@ -111,7 +120,8 @@ __device__ __forceinline__ int lb_bin(uint32_t lb)
 }
 
 constexpr int kMaxChain = 20;     // chain steps of 16 rows: ndy <= 257 (R <= 128) needs 17
-constexpr int kSeaThreads = 512;  // 8 waves
+constexpr int kSeaThreads = 512;  // 8 waves (exact kernel)
+constexpr int kBoundsThreads = 512;  // 8 waves, 4 workgroups per CU
 constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or already scheduled
 
 // Bounds are kept as u16 = floor(LB / 16) (LB <= 16 * 65280): still a lower bound, 15 units coarser.
@@ -132,11 +142,12 @@ __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est
 //   out: gl[plane][ctu][max_groups] u16 bound per group (kNone where scheduled / illegal),
 //        list0[plane][ctu][..] the first batch (the kFirst groups of the lowest histogram bins), hdr
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
-                                                                 const uint16_t *__restrict__ bbuf,
+__global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
+                                                                 const uint32_t *__restrict__ pbuf,
                                                                  uint16_t *__restrict__ gl, uint16_t *__restrict__ list0,
                                                                  SeaHdr *__restrict__ hdr, uint32_t *__restrict__ order,
-                                                                 uint32_t *__restrict__ ctrl, const MeGeom g, int max_groups)
+                                                                 uint32_t *__restrict__ ctrl, const MeGeom g, int gl_pitch,
+                                                                 uint32_t *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint16_t *glb = reinterpret_cast<uint16_t *>(smem);  // [ndy][ngx]
@@ -151,9 +162,10 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
     const int cx = ctx * 64, cy = cty * 64;
     const SeaLayout L = sea_layout(g.width, g.height, g.range, cx, cy);
     const uint8_t *cur = cur_base + f * g.cur_fs;
-    const uint16_t *B = bbuf + (int64_t)blockIdx.z * g.height * g.width;
+    const uint32_t *P = pbuf + (int64_t)blockIdx.z * g.height * g.width;
     const int64_t ctu_id = ((int64_t)blockIdx.z * g.ctus_y + cty) * g.ctus_x + ctx;
 
+    const long long tb0 = stats ? clock64() : 0;
     if (tid < kBins) hist[tid] = 0;
     if (tid == 0) {
         list_n = 0;
@@ -173,9 +185,10 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
         if (rrow == 0) csum[b] = s;
     }
     __syncthreads();
-    uint32_t cs[16];
+    const long long tb1 = stats ? clock64() : 0;
+    uint32_t cs2[8];  // [4 rows of sub-blocks][2 pairs]: sums of sub-blocks (j, 2kp) | (j, 2kp+1) << 16, <= 65280 each
 #pragma unroll
-    for (int b = 0; b < 16; b++) cs[b] = __builtin_amdgcn_readfirstlane(csum[b]);
+    for (int b = 0; b < 8; b++) cs2[b] = __builtin_amdgcn_readfirstlane(csum[2 * b] | (csum[2 * b + 1] << 16));
 
     // ---- bounds.  Group = 4 window-aligned dx at one dy.  The bound of the group at row dyi needs the
     //      box sums of rows dyi, dyi+16, dyi+32, dyi+48 -- and so do its neighbours 16 rows up and
@@ -185,10 +198,14 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
     const int ndx = L.dxhi - L.dxlo + 1;
     {
         const int nchain = 16 * L.ngx;  // (c, gx)
-        for (int t = tid; t < nchain; t += kSeaThreads) {
+        // whole sweeps of chains; a short remainder (the 33rd column of groups of a +-64 window: 16 of
+        // 528 chains) is done group by group below instead of costing a second walk
+        int nwalk = nchain - nchain % kBoundsThreads;
+        if (nchain - nwalk >= kBoundsThreads / 4) nwalk = nchain;
+        for (int t = tid; t < nwalk; t += kBoundsThreads) {
             const int c = t / L.ngx, gx = t - c * L.ngx;
             if (c >= L.ndy) continue;
-            const uint16_t *bp = B + (int64_t)(cy + L.dylo + c) * g.width + L.wx0 + 4 * gx;
+            const uint32_t *pp = P + (int64_t)(cy + L.dylo + c) * g.width + L.wx0 + 4 * gx;
             const int64_t band = (int64_t)16 * g.width;
             uint32_t legal = 0;
 #pragma unroll
@@ -197,11 +214,11 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
                 if (dxi >= 0 && dxi < ndx) legal |= 1u << q;
             }
             // five band registers used round-robin: while step m is being summed, band m+4 is in flight
-            uint2 bnd[5][4];
+            uint4 bnd[5][2];
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int k = 0; k < 4; k++) bnd[j][k] = *reinterpret_cast<const uint2 *>(bp + j * band + 16 * k);
+                for (int kp = 0; kp < 2; kp++) bnd[j][kp] = *reinterpret_cast<const uint4 *>(pp + j * band + 32 * kp);
             for (int m0 = 0; m0 < kMaxChain; m0 += 5)  // unrolled by the rotation period: static register indices
 #pragma unroll
                 for (int mm = 0; mm < 5; mm++) {
@@ -210,21 +227,20 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
                     if (dyi >= L.ndy) break;
                     if (dyi + 16 < L.ndy) {
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                            bnd[(mm + 4) % 5][k] = *reinterpret_cast<const uint2 *>(bp + (m + 4) * band + 16 * k);
+                        for (int kp = 0; kp < 2; kp++)
+                            bnd[(mm + 4) % 5][kp] = *reinterpret_cast<const uint4 *>(pp + (m + 4) * band + 32 * kp);
                     }
                     uint32_t lb[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
                     for (int j = 0; j < 4; j++)
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint2 v = bnd[(mm + j) % 5][k];
-                            const uint32_t sc = cs[4 * j + k];
-                            const uint32_t v0 = v.x & 0xffffu, v1 = v.x >> 16, v2 = v.y & 0xffffu, v3 = v.y >> 16;
-                            lb[0] += v0 > sc ? v0 - sc : sc - v0;  // v_sad_u32
-                            lb[1] += v1 > sc ? v1 - sc : sc - v1;
-                            lb[2] += v2 > sc ? v2 - sc : sc - v2;
-                            lb[3] += v3 > sc ? v3 - sc : sc - v3;
+                        for (int kp = 0; kp < 2; kp++) {
+                            const uint4 v = bnd[(mm + j) % 5][kp];
+                            const uint32_t sc = cs2[2 * j + kp];
+                            lb[0] = __builtin_amdgcn_sad_u16(v.x, sc, lb[0]);  // both sub-blocks of the pair at once
+                            lb[1] = __builtin_amdgcn_sad_u16(v.y, sc, lb[1]);
+                            lb[2] = __builtin_amdgcn_sad_u16(v.z, sc, lb[2]);
+                            lb[3] = __builtin_amdgcn_sad_u16(v.w, sc, lb[3]);
                         }
                     uint32_t mn = 0xffffffffu;
 #pragma unroll
@@ -235,9 +251,47 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
                     if (st != kNone) atomicAdd(&hist[lb_bin(st)], 1u);
                 }
         }
+        // remainder chains, one group per lane: item i = (step m, chain r)
+        const int nrem = nchain - nwalk;
+        const int nsteps = (L.ndy + 15) >> 4;
+        for (int i = tid; i < nrem * nsteps; i += kBoundsThreads) {
+            const int m = i / nrem, t = nwalk + (i - m * nrem);
+            const int c = t / L.ngx, gx = t - c * L.ngx;
+            const int dyi = c + 16 * m;
+            if (dyi >= L.ndy) continue;
+            const uint32_t *pp = P + (int64_t)(cy + L.dylo + dyi) * g.width + L.wx0 + 4 * gx;
+            const int64_t band = (int64_t)16 * g.width;
+            uint4 bnd[4][2];
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int kp = 0; kp < 2; kp++) bnd[j][kp] = *reinterpret_cast<const uint4 *>(pp + j * band + 32 * kp);
+            uint32_t lb[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int kp = 0; kp < 2; kp++) {
+                    const uint4 v = bnd[j][kp];
+                    const uint32_t sc = cs2[2 * j + kp];
+                    lb[0] = __builtin_amdgcn_sad_u16(v.x, sc, lb[0]);
+                    lb[1] = __builtin_amdgcn_sad_u16(v.y, sc, lb[1]);
+                    lb[2] = __builtin_amdgcn_sad_u16(v.z, sc, lb[2]);
+                    lb[3] = __builtin_amdgcn_sad_u16(v.w, sc, lb[3]);
+                }
+            uint32_t mn = 0xffffffffu;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int dxi = 4 * gx + q - a;
+                if (dxi >= 0 && dxi < ndx) mn = min(mn, lb[q]);
+            }
+            const uint32_t st = mn == 0xffffffffu ? kNone : lb_store(mn);
+            glb[dyi * L.ngx + gx] = (uint16_t)st;
+            if (st != kNone) atomicAdd(&hist[lb_bin(st)], 1u);
+        }
     }
     __syncthreads();
 
+    const long long tb2 = stats ? clock64() : 0;
     // ---- first batch: the kFirst groups of the lowest bins.  pick_bin = the bin in which the running
     //      count reaches kFirst; below_n = groups in the bins under it (all taken), the rest of the
     //      quota comes from pick_bin itself, whichever of its groups the scan reaches first ----
@@ -277,39 +331,67 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
     const int nbelow = below_n;            // list0[0 .. nbelow) = bins < pb
     const int quota = kFirst - nbelow;     // list0[nbelow .. nbelow + min(quota, |bin pb|)) = bin pb
 
+    const long long tb3 = stats ? clock64() : 0;
     // ---- write the bounds out; groups of the first batch go to list0 (scan order within a wave) and
     //      are marked; the smallest bound left over goes to the header ----
-    uint16_t *glo = gl + ctu_id * max_groups;
-    uint16_t *lo = list0 + ctu_id * max_groups;
+    // A thread takes 8 consecutive groups (one 16-byte LDS read, one 16-byte store); a wave reserves its
+    // list slots with ONE LDS atomic per counter per sweep.
+    uint16_t *glo = gl + ctu_id * gl_pitch;
+    uint16_t *lo = list0 + ctu_id * gl_pitch;
     uint32_t rest_min = kNone;
-    for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
-        const int gi = g0 + tid;
-        const uint32_t v = gi < L.ngroups ? (uint32_t)glb[gi] : kNone;
-        const int bin = v != kNone ? lb_bin(v) : kBins + 1;
-        const bool lo_take = bin < pb || (pb == kBins && bin < kBins);
-        const bool eq = bin == pb && pb < kBins;
-        const unsigned long long tl = __ballot(lo_take), te = __ballot(eq);
+    const int nvec = (L.ngroups + 7) >> 3;
+    for (int v0 = 0; v0 < nvec; v0 += kBoundsThreads) {
+        const int vi = v0 + tid;
+        uint4 wv = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        if (vi < nvec) wv = reinterpret_cast<const uint4 *>(glb)[vi];
+        uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
+        uint32_t lom = 0, eqm = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const uint32_t v = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            const bool valid = vi < nvec && 8 * vi + e < L.ngroups && v != kNone;
+            const int bin = valid ? lb_bin(v) : kBins + 1;
+            if (bin < pb) lom |= 1u << e;                 // pb == kBins: every legal group
+            if (bin == pb && pb < kBins) eqm |= 1u << e;
+            if (!valid) w[e >> 1] |= 0xffffu << (16 * (e & 1));  // what lies past the last group reads as kNone
+        }
+        // inclusive wave scan of (taken below pb | in pb << 16)
+        const uint32_t cnt = (uint32_t)__popc(lom) | ((uint32_t)__popc(eqm) << 16);
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        const uint32_t tot = __shfl(inc, 63);
         int wl = 0, we = 0;
         if (lane == 0) {
-            if (tl) wl = atomicAdd(&list_n, (int)__popcll(tl));
-            if (te) we = atomicAdd(&eq_n, (int)__popcll(te));
+            if (tot & 0xffffu) wl = atomicAdd(&list_n, (int)(tot & 0xffffu));
+            if (tot >> 16) we = atomicAdd(&eq_n, (int)(tot >> 16));
         }
-        wl = __shfl(wl, 0);
-        we = __shfl(we, 0);
-        bool take = lo_take;
-        int slot = wl + (int)__popcll(tl & ((1ull << lane) - 1ull));
-        if (eq) {
-            const int r = we + (int)__popcll(te & ((1ull << lane) - 1ull));
-            take = r < quota;
-            slot = nbelow + r;
+        int sl = __shfl(wl, 0) + (int)((inc - cnt) & 0xffffu);          // next slot among the groups under pb
+        int se = __shfl(we, 0) + (int)((inc - cnt) >> 16);              // rank within bin pb
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int gi = 8 * vi + e;
+            bool take = false;
+            int slot = 0;
+            if (lom & (1u << e)) {
+                take = true;
+                slot = sl++;
+            } else if (eqm & (1u << e)) {
+                take = se < quota;
+                slot = nbelow + se++;
+            }
+            const uint32_t v = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            if (take) {
+                lo[slot] = (uint16_t)gi;  // schedule entry = the group's index dyi * ngx + gx
+                w[e >> 1] |= 0xffffu << (16 * (e & 1));  // scheduled: kNone
+            } else if (v != kNone) {
+                rest_min = min(rest_min, v);
+            }
         }
-        if (take) {
-            const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
-            lo[slot] = (uint16_t)((dyi << 7) | gx);
-        } else if (v != kNone) {
-            rest_min = min(rest_min, v);
-        }
-        if (gi < L.ngroups) glo[gi] = take ? (uint16_t)kNone : (uint16_t)v;
+        if (vi < nvec) reinterpret_cast<uint4 *>(glo)[vi] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rest_min = min(rest_min, (uint32_t)__shfl_xor((int)rest_min, o));
@@ -324,6 +406,12 @@ __global__ __launch_bounds__(kSeaThreads) void sea_bounds_kernel(const uint8_t *
         hdr[ctu_id] = h;
         // launch order of kernel 2: longest first, in kClasses classes of the estimate (a queue each)
         const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
+        if (stats) {
+            stats[16 * ctu_id + 10] = (uint32_t)(tb1 - tb0);        // cycles: sub-block sums of the CTU
+            stats[16 * ctu_id + 11] = (uint32_t)(tb2 - tb1);        //         bounds
+            stats[16 * ctu_id + 12] = (uint32_t)(tb3 - tb2);        //         histogram scan
+            stats[16 * ctu_id + 13] = (uint32_t)(clock64() - tb3);  //         write-out
+        }
         const int cls = sea_class(est_n);
         order[(size_t)cls * total + atomicAdd(&ctrl[cls], 1u)] = (uint32_t)ctu_id;
     }
@@ -344,7 +432,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
                                                                    const uint32_t *__restrict__ order,
                                                                    uint32_t *__restrict__ ctrl, int total,
                                                                    x265amd_mv *__restrict__ out, const MeGeom g,
-                                                                   int max_groups, int win_dwords,
+                                                                   int gl_pitch, int win_dwords,
                                                                    uint32_t *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -407,12 +495,12 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     const SeaLayout L = sea_layout(g.width, g.height, R, cx, cy);
     const uint8_t *cur = cur_base + f * g.cur_fs;
     const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
-    const uint16_t *glo = gl + ctu_id * max_groups;
-    const uint16_t *l0 = list0 + ctu_id * max_groups;
+    const uint16_t *glo = gl + ctu_id * gl_pitch;
+    const uint16_t *l0 = list0 + ctu_id * gl_pitch;
 
     // the first batch's entries of this lane (rounds 0 and 1) and the header: in flight with the window
     const long long t_begin = stats ? clock64() : 0;
-    const int e_hi = max_groups - 1;
+    const int e_hi = gl_pitch - 1;
     int ent0 = (int)l0[min(set * 64 + lane, e_hi)];
     int ent1 = (int)l0[min(128 + set * 64 + lane, e_hi)];
     const SeaHdr h = hdr[ctu_id];
@@ -454,7 +542,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     // one round for this wave: `ent` = the lane's group (valid where `have`)
     auto run_round = [&](int ent, bool have) {
         ent = have ? ent : 0;
-        const int dyi = ent >> 7, gx = ent & 127;
+        const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx;
         uint32_t *pbuf = part[round & 1];
         if (__ballot(have) != 0ull) {  // wave-uniform
             const uint32_t *wrow = win + (dyi + 16 * qtr) * L.pitch + gx;
@@ -556,10 +644,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
                 const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
                 const bool take = v != kNone && (v << 4) <= best_sad;
                 const unsigned long long tm = __ballot(take);
-                if (take) {
-                    const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
-                    list[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)((dyi << 7) | gx);
-                }
+                if (take) list[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)gi;
                 wbase += (int)__popcll(tm);
             }
         }
@@ -652,8 +737,8 @@ extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, i
     int max_rows, max_pitch, max_ngx, max_ndy;
     sea_extents(width, height, range, max_rows, max_pitch, max_ngx, max_ndy);
     const size_t planes = (size_t)nframes * nrefs, nctu = (size_t)(width / 64) * (height / 64);
-    const size_t per_ctu = (size_t)max_ngx * max_ndy;
-    return align256(2 * sizeof(uint16_t) * width * height * planes)        // H16 + B16 per (frame, ref) plane
+    const size_t per_ctu = ((size_t)max_ngx * max_ndy + 7) & ~(size_t)7;  // 16-byte rows
+    return align256(6 * (size_t)width * height * planes)                    // H16 (u16) + pair plane (u32) per (frame, ref) plane
            + 2 * align256(sizeof(uint16_t) * per_ctu * nctu * planes)      // bounds + first-batch list per CTU
            + align256(sizeof(SeaHdr) * nctu * planes)
            + align256(sizeof(uint32_t) * kClasses * nctu * planes)         // launch-order queues of the exact kernel
@@ -681,7 +766,8 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     int max_rows, max_pitch, max_ngx, max_ndy;
     sea_extents(width, height, range, max_rows, max_pitch, max_ngx, max_ndy);
     const int max_groups = max_ngx * max_ndy;
-    if (max_ngx > 127 || max_ndy > 511 || max_ndy > 16 * kMaxChain) return X265AMD_ERR_LDS;  // 16-bit schedule entries
+    const int gl_pitch = (max_groups + 7) & ~7;
+    if (max_groups > 0xffff || max_ndy > 16 * kMaxChain) return X265AMD_ERR_LDS;  // 16-bit schedule entries
     const int win_dwords = max_rows * max_pitch;
     size_t lds_exact = (size_t)win_dwords * 4 + (((size_t)max_groups * 2 + 15) & ~(size_t)15);
     if (const char *pad = getenv("X265AMD_SEA_LDS_PAD")) lds_exact += (size_t)atoi(pad);  // occupancy experiments only
@@ -690,13 +776,13 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
 
     const size_t nctu = (size_t)(width / 64) * (height / 64);
     uint8_t *ws = (uint8_t *)d_workspace;
-    uint16_t *hbuf = (uint16_t *)ws;
-    uint16_t *bbuf = hbuf + (size_t)nplanes * width * height;
-    ws += align256(2 * sizeof(uint16_t) * width * height * (size_t)nplanes);
+    uint32_t *pbuf = (uint32_t *)ws;  // pair plane first (16-byte loads), H16 behind it
+    uint16_t *hbuf = (uint16_t *)(pbuf + (size_t)nplanes * width * height);
+    ws += align256(6 * (size_t)width * height * (size_t)nplanes);
     uint16_t *gl = (uint16_t *)ws;
-    ws += align256(sizeof(uint16_t) * (size_t)max_groups * nctu * (size_t)nplanes);
+    ws += align256(sizeof(uint16_t) * (size_t)gl_pitch * nctu * (size_t)nplanes);
     uint16_t *list0 = (uint16_t *)ws;
-    ws += align256(sizeof(uint16_t) * (size_t)max_groups * nctu * (size_t)nplanes);
+    ws += align256(sizeof(uint16_t) * (size_t)gl_pitch * nctu * (size_t)nplanes);
     SeaHdr *hdr = (SeaHdr *)ws;
     ws += align256(sizeof(SeaHdr) * nctu * (size_t)nplanes);
     uint32_t *order = (uint32_t *)ws;
@@ -712,7 +798,7 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
                        width, height, stride, nrefs, ref_frame_stride, ref_ref_stride);
     if (timing) (void)hipEventRecord(g_me_ev[1], st);
     hipLaunchKernelGGL(box16_v, dim3((width / 2 + 255) / 256, (height + kBoxVRows - 1) / kBoxVRows, (unsigned)nplanes),
-                       dim3(256), 0, st, hbuf, bbuf, width, height);
+                       dim3(256), 0, st, hbuf, pbuf, width, height);
     if (timing) (void)hipEventRecord(g_me_ev[2], st);
     MeGeom g;
     g.width = width;
@@ -727,8 +813,8 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     g.ref_rs = ref_ref_stride;
     const dim3 grid(g.ctus_x, g.ctus_y, (unsigned)nplanes);
     X265AMD_HIP(hipMemsetAsync(ctrl, 0, 4 * (kClasses + 1), st));
-    hipLaunchKernelGGL(sea_bounds_kernel, grid, dim3(kSeaThreads), lds_bounds, st, d_cur, bbuf, gl, list0, hdr, order,
-                       ctrl, g, max_groups);
+    hipLaunchKernelGGL(sea_bounds_kernel, grid, dim3(kBoundsThreads), lds_bounds, st, d_cur, pbuf, gl, list0, hdr, order,
+                       ctrl, g, gl_pitch, g_me_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
     X265AMD_HIP(hipFuncSetAttribute((const void *)sea_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_exact));
@@ -738,7 +824,7 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     if (per_cu < 1) return X265AMD_ERR_LDS;
     const int resident = per_cu * cu_count();
     hipLaunchKernelGGL(sea_exact_kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(kSeaThreads), lds_exact,
-                       st, d_cur, d_ref, gl, list0, hdr, order, ctrl, total, d_out, g, max_groups, win_dwords, g_me_stats);
+                       st, d_cur, d_ref, gl, list0, hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
     if (timing) (void)hipEventRecord(g_me_ev[4], st);
     return hip_status(hipGetLastError());
 }
