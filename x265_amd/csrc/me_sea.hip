@@ -155,6 +155,8 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     __shared__ uint32_t csum[16];
     __shared__ int list_n, eq_n, pick_bin, below_n, est_n;
     __shared__ uint32_t rest_lb;
+    __shared__ uint32_t bank_cnt[32];
+    __shared__ uint16_t sel_ent[kFirst];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int ctx = blockIdx.x, cty = blockIdx.y;
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
 
     const long long tb0 = stats ? clock64() : 0;
     if (tid < kBins) hist[tid] = 0;
+    if (tid < 32) bank_cnt[tid] = 0;
     if (tid == 0) {
         list_n = 0;
         eq_n = 0;
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             }
             const uint32_t v = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
             if (take) {
-                lo[slot] = (uint16_t)gi;  // schedule entry = the group's index dyi * ngx + gx
+                sel_ent[slot] = (uint16_t)gi;  // schedule entry = the group's index dyi * ngx + gx
                 w[e >> 1] |= 0xffffu << (16 * (e & 1));  // scheduled: kNone
             } else if (v != kNone) {
                 rest_min = min(rest_min, v);
@@ -397,9 +400,31 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     for (int o = 32; o > 0; o >>= 1) rest_min = min(rest_min, (uint32_t)__shfl_xor((int)rest_min, o));
     if (lane == 0 && rest_min != kNone) atomicMin(&rest_lb, rest_min);
     __syncthreads();
+    // ---- order the first batch for kernel 2's LDS reads: a lane there reads window dwords
+    //      (dyi + row) * pitch + gx + k, so the 32 lanes of a half wave collide whenever their
+    //      dyi * pitch + gx agree mod 32.  Deal the entries out bank by bank (rank within the bank first,
+    //      then bank): any 32 consecutive slots then hold at most two entries of one bank. ----
+    const int n0 = pb == kBins ? list_n : nbelow + min(quota, eq_n);
+    int my_ent = 0, my_bank = 0, my_rank = 0;
+    if (tid < n0) {
+        my_ent = sel_ent[tid];
+        const int dyi = my_ent / L.ngx, gx = my_ent - dyi * L.ngx;
+        my_bank = (dyi * L.pitch + gx) & 31;
+        my_rank = (int)atomicAdd(&bank_cnt[my_bank], 1u);
+    }
+    __syncthreads();
+    if (tid < n0) {
+        int pos = 0;
+#pragma unroll
+        for (int b = 0; b < 32; b++) {
+            const int cb = (int)bank_cnt[b];
+            pos += min(cb, my_rank) + ((b < my_bank && cb > my_rank) ? 1 : 0);
+        }
+        lo[pos] = (uint16_t)my_ent;
+    }
     if (tid == 0) {
         SeaHdr h;
-        h.n0 = (uint32_t)(pb == kBins ? list_n : nbelow + min(quota, eq_n));
+        h.n0 = (uint32_t)n0;
         h.rest_min = rest_lb;  // kNone: nothing left over
         h.est = (uint32_t)est_n;
         h.pad = 0;
