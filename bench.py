@@ -77,9 +77,9 @@ def cpu_baseline(frames_np, ctu, rng, nrefs, tu, qp, gpu_mv, gpu_level, gpu_rec,
     h, w = frames_np.shape[1:]
     nctu = (h // ctu) * (w // ctu)
     cur, ref = frames_np[nrefs], frames_np[nrefs - 1]
-    # size the sample for ~10-30 s of CPU work: one CTU costs ~ (2R+1)^2 * ctu^2 / 0.7e9 s per core
+    # size the sample for ~10-30 core-seconds of CPU work: one CTU costs ~ (2R+1)^2 * ctu^2 / 0.7e9 s per core
     per_ctu = (2 * rng + 1) ** 2 * ctu * ctu / 0.7e9
-    count = int(max(threads * 2, min(nctu // 2, 20.0 / per_ctu)))
+    count = int(max(threads * 2, min(nctu, 30.0 / per_ctu)))
     step = max(nctu // count, 1)
     t0 = time.perf_counter()
     mv = me_lib.me_fullsearch(cur, ref, ctu, rng, first=step // 2, step=step, count=count, nthreads=threads)

@@ -3,8 +3,9 @@
 
     python tools/pmc_traffic.py <workload> <launches> <fetch_dir> <write_dir> [out.json]
 
-`launches` = number of hot-path steps the profiled command ran (warmup + steps): the counters
-are summed per kernel over the whole run and divided by it, giving bytes PER LAUNCH.
+The counters are averaged per DISPATCH of each kernel; every kernel of the path is dispatched
+once per step, so that is bytes per launch (`launches` = warmup + steps is recorded for reference;
+bench.py's per-kernel timing passes add dispatches, which is why the average is per dispatch).
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and
 WRITE_SIZE are in KiB-like units of 1 KB; on gfx950 FETCH_SIZE reports half of the bytes of wide
 coalesced reads, so the fetch figure is given raw and doubled (`fetch_bytes_x2`), and the doubled
@@ -36,14 +37,14 @@ def main():
     workload, launches, fdir, wdir = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4]
     out = sys.argv[5] if len(sys.argv) > 5 else os.path.join(os.path.dirname(__file__), "..", "profiles", "pmc_traffic.json")
     fetch, nf = load(fdir, "FETCH_SIZE")
-    write, _ = load(wdir, "WRITE_SIZE")
+    write, nw = load(wdir, "WRITE_SIZE")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         kernels[k] = {
-            "dispatches_per_launch": nf.get(k, 0) / launches,
-            "fetch_bytes_raw": fetch.get(k, 0.0) * 1024 / launches,
-            "fetch_bytes_x2": fetch.get(k, 0.0) * 2048 / launches,
-            "write_bytes": write.get(k, 0.0) * 1024 / launches,
+            "dispatches": nf.get(k, 0) or nw.get(k, 0),
+            "fetch_bytes_raw": fetch.get(k, 0.0) * 1024 / max(nf.get(k, 0), 1),
+            "fetch_bytes_x2": fetch.get(k, 0.0) * 2048 / max(nf.get(k, 0), 1),
+            "write_bytes": write.get(k, 0.0) * 1024 / max(nw.get(k, 0), 1),
         }
     me = [k for k in kernels if k.startswith(("sea_", "box16", "me_fullsearch"))]
     tq = [k for k in kernels if k.startswith("tq_kernel")]

@@ -30,8 +30,10 @@ namespace x265amd {
 // horizontal: H16[y][x] = sum_{k<16} p[y][x+k]; a thread makes 4 consecutive x from 5 aligned dwords
 __global__ __launch_bounds__(256) void box16_h(const uint8_t *__restrict__ ref_base, uint16_t *__restrict__ hbuf,
                                                int width, int height, int stride, int nrefs, int64_t ref_fs,
-                                               int64_t ref_rs)
+                                               int64_t ref_rs, uint32_t *__restrict__ ctrl)
 {
+    // the queue counters of the later kernels start from zero (stream order: this grid ends first)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) ctrl[threadIdx.x] = 0;
     const int xq = blockIdx.x * 256 + threadIdx.x;  // group of 4 pixels
     const int y = blockIdx.y;
     const int pl = blockIdx.z;
@@ -134,7 +136,7 @@ struct SeaHdr {  // per (plane, CTU)
     uint32_t pad;
 };
 constexpr int kFirst = 256;   // first batch: two rounds of 128 groups
-constexpr int kClasses = 4;   // launch-order classes of the work estimate, heaviest first
+constexpr int kClasses = 4;   // launch-order classes (kClasses + 1 <= 8 counters: box16_h zeroes 8) of the work estimate, heaviest first
 __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est >= 1024 ? 1 : est >= 600 ? 2 : 3; }
 
 // ---------------------------------------------------------------------------------------------
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
 // comes from list0 with its entries already in registers when the window has landed; a second pass is
 // needed only if a group outside it has a bound <= the best SAD found (hdr.rest_min tells without a scan).
 // ---------------------------------------------------------------------------------------------
+template <bool kStats>
 __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t *__restrict__ cur_base,
                                                                    const uint8_t *__restrict__ ref_base,
                                                                    const uint16_t *__restrict__ gl,
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     const uint16_t *l0 = list0 + ctu_id * gl_pitch;
 
     // the first batch's entries of this lane (rounds 0 and 1) and the header: in flight with the window
-    const long long t_begin = stats ? clock64() : 0;
+    const long long t_begin = kStats ? clock64() : 0;
     const int e_hi = gl_pitch - 1;
     int ent0 = (int)l0[min(set * 64 + lane, e_hi)];
     int ent1 = (int)l0[min(128 + set * 64 + lane, e_hi)];
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     const uint32_t rest_min = __builtin_amdgcn_readfirstlane(h.rest_min);
     __syncthreads();
 
-    const long long t_staged = stats ? clock64() : 0;
+    const long long t_staged = kStats ? clock64() : 0;
     const uint32_t *__restrict__ cbase = reinterpret_cast<const uint32_t *>(cur + (int64_t)cy * g.stride + cx);
 
     // one round for this wave: `ent` = the lane's group (valid where `have`)
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     if (n0 > 128) run_round(ent1, 128 + set * 64 + lane < n0);
     __syncthreads();
 
-    const long long t_pass0 = stats ? clock64() : 0;
+    const long long t_pass0 = kStats ? clock64() : 0;
     // ---- pass 1, only if some group left over has a bound <= the best SAD so far ----
     int n1 = 0;
     const uint32_t best_sad = (uint32_t)(best_key >> 32);
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
         mv.mvy = (int16_t)(c / span - R);
         mv.sad = (uint32_t)(best >> 32);
         out[ctu_id] = mv;
-        if (stats) {
+        if constexpr (kStats) {
             stats[16 * ctu_id + 0] = (uint32_t)n0;
             stats[16 * ctu_id + 1] = (uint32_t)n1;
             stats[16 * ctu_id + 2] = (uint32_t)(t_staged - t_begin);  // cycles: window staging
@@ -820,7 +823,7 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     const bool timing = g_me_timing;
     if (timing) (void)hipEventRecord(g_me_ev[0], st);
     hipLaunchKernelGGL(box16_h, dim3((width / 4 + 255) / 256, height, (unsigned)nplanes), dim3(256), 0, st, d_ref, hbuf,
-                       width, height, stride, nrefs, ref_frame_stride, ref_ref_stride);
+                       width, height, stride, nrefs, ref_frame_stride, ref_ref_stride, ctrl);
     if (timing) (void)hipEventRecord(g_me_ev[1], st);
     hipLaunchKernelGGL(box16_v, dim3((width / 2 + 255) / 256, (height + kBoxVRows - 1) / kBoxVRows, (unsigned)nplanes),
                        dim3(256), 0, st, hbuf, pbuf, width, height);
@@ -837,19 +840,26 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     g.ref_fs = ref_frame_stride;
     g.ref_rs = ref_ref_stride;
     const dim3 grid(g.ctus_x, g.ctus_y, (unsigned)nplanes);
-    X265AMD_HIP(hipMemsetAsync(ctrl, 0, 4 * (kClasses + 1), st));
     hipLaunchKernelGGL(sea_bounds_kernel, grid, dim3(kBoundsThreads), lds_bounds, st, d_cur, pbuf, gl, list0, hdr, order,
                        ctrl, g, gl_pitch, g_me_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
-    X265AMD_HIP(hipFuncSetAttribute((const void *)sea_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    X265AMD_HIP(hipFuncSetAttribute((const void *)sea_exact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds_exact));
     // as many workgroups as the chip holds at once (LDS- and register-bound), each looping over CTUs
     int per_cu = 0;
-    X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)sea_exact_kernel, kSeaThreads, lds_exact));
+    X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)sea_exact_kernel<false>, kSeaThreads, lds_exact));
     if (per_cu < 1) return X265AMD_ERR_LDS;
     const int resident = per_cu * cu_count();
-    hipLaunchKernelGGL(sea_exact_kernel, dim3((unsigned)(total < resident ? total : resident)), dim3(kSeaThreads), lds_exact,
-                       st, d_cur, d_ref, gl, list0, hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
+    const dim3 egrid((unsigned)(total < resident ? total : resident));
+    if (g_me_stats) {
+        X265AMD_HIP(hipFuncSetAttribute((const void *)sea_exact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_exact));
+        hipLaunchKernelGGL(sea_exact_kernel<true>, egrid, dim3(kSeaThreads), lds_exact, st, d_cur, d_ref, gl, list0, hdr,
+                           order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
+    } else {
+        hipLaunchKernelGGL(sea_exact_kernel<false>, egrid, dim3(kSeaThreads), lds_exact, st, d_cur, d_ref, gl, list0, hdr,
+                           order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
+    }
     if (timing) (void)hipEventRecord(g_me_ev[4], st);
     return hip_status(hipGetLastError());
 }
