@@ -154,7 +154,7 @@ typedef struct x265amd_tq_desc {
      * prediction output / co-located block).  With d_mv != NULL: the REFERENCE
      * picture; the prediction of pixel (x, y) is ref[y + mvy][x + mvx] with the
      * vector of the mv_ctu x mv_ctu block containing (x, y) -- integer-pel motion
-     * compensation fused into the load. */
+     * compensation fused into the load (see mv_shift below). */
     const uint8_t *d_pred;
     int32_t pred_stride;
     int64_t pred_frame_stride;
@@ -179,6 +179,12 @@ typedef struct x265amd_tq_desc {
     uint8_t *d_rec; /* reconstruction: OUT of inverse/roundtrip */
     int32_t rec_stride;
     int64_t rec_frame_stride;
+
+    /* with d_mv: the vectors are applied as (mvx >> mv_shift, mvy >> mv_shift), arithmetic shift.
+     * 0 for the plane the search ran on; 1 for the 4:2:0 chroma planes of the same picture (luma
+     * vectors, mv_ctu = half the luma CTU).  0..3. */
+    int32_t mv_shift;
+    int32_t reserved; /* 0 */
 } x265amd_tq_desc;
 
 /* xSubDct + xQuant for every TU of the plane(s)

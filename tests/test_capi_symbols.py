@@ -55,4 +55,4 @@ def test_desc_struct_layout_matches_header():
     decl = re.findall(r"\b(?:const\s+)?[a-z0-9_]+(?:\s*\*)?\s*\**\s*([a-z_0-9]+(?:\s*,\s*[a-z_0-9]+)*)\s*;", body)
     flat = [n.strip() for d in decl for n in d.split(",")]
     assert flat == names
-    assert C.sizeof(api.TqDesc) == 184   # sizeof(x265amd_tq_desc) from gcc
+    assert C.sizeof(api.TqDesc) == 192   # sizeof(x265amd_tq_desc) from gcc

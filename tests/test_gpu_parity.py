@@ -315,3 +315,48 @@ def test_me_then_tq_pipeline_vs_oracle(gpu, oracle):
     np.testing.assert_array_equal(host(level)[0], ol)
     np.testing.assert_array_equal(host(sums)[0].astype(np.uint32), os_)
     assert hashlib.md5(host(rec)[0].tobytes()).hexdigest() == hashlib.md5(orc.tobytes()).hexdigest()
+
+
+def test_closed_loop_gop_vs_oracle(gpu, oracle):
+    """closed-loop P pictures with xEncEncode's reference rotation
+    (src/encode.cpp:619-621,965-970), two GOP segments batched.  The CPU chain is the oracle's search
+    and TQ applied picture by picture to its OWN reconstruction; vectors, levels and the MD5 of every
+    reconstructed Y+U+V picture (what src/encode.cpp:945-950 hashes) must agree."""
+    import hashlib
+    from x265_amd import synth, ClosedLoopGop
+    W, H, R, QP, T = 256, 128, 16, 30, 4
+    segs = []
+    for seed in (5, 6):
+        y, u, v = synth.make_sequence(W, H, T, search_range=R, seed=seed, chroma=True)
+        segs.append(np.concatenate([y.reshape(T, -1), u.reshape(T, -1), v.reshape(T, -1)], axis=1))
+    yuv = np.stack(segs)                                   # [S][T][W*H*3/2]
+    S, ysz, csz = 2, W * H, (W // 2) * (H // 2)
+    enc = ClosedLoopGop(W, H, S, search_range=R, qp=QP)
+    enc.set_reference(dev(yuv[:, 0]))                      # the I picture's reconstruction: here the source itself
+    qpc = oracle.chroma_qp(QP)
+    ref_cpu = [yuv[s, 0].copy() for s in range(S)]
+    for t in range(1, T):
+        rec_gpu = host(enc.encode_p(dev(yuv[:, t])))
+        gmv = gpu.mv_to_numpy(enc.mv)[:, 0]
+        glevel = host(enc.level)
+        for s in range(S):
+            cur, ref = yuv[s, t], ref_cpu[s]
+            cy, ry = cur[:ysz].reshape(H, W), ref[:ysz].reshape(H, W)
+            omv = oracle.me_fullsearch(cy, ry, 64, R, nthreads=8)
+            np.testing.assert_array_equal(gmv[s], omv)
+            ly, _ = oracle.tq_forward(cy, ry, 32, QP, 1, mv=omv, mv_ctu=64)
+            rec = [oracle.tq_inverse(ly, ry, 32, QP, 1, mv=omv, mv_ctu=64).reshape(-1)]
+            lev = [ly.reshape(-1)]
+            cmv = omv.copy()
+            cmv["mvx"] >>= 1
+            cmv["mvy"] >>= 1
+            for k in range(2):
+                a, b = ysz + k * csz, ysz + (k + 1) * csz
+                cc, rc = cur[a:b].reshape(H // 2, W // 2), ref[a:b].reshape(H // 2, W // 2)
+                lc, _ = oracle.tq_forward(cc, rc, 16, qpc, 1, mv=cmv, mv_ctu=32)
+                rec.append(oracle.tq_inverse(lc, rc, 16, qpc, 1, mv=cmv, mv_ctu=32).reshape(-1))
+                lev.append(lc.reshape(-1))
+            ref_cpu[s] = np.concatenate(rec)
+            np.testing.assert_array_equal(glevel[s], np.concatenate(lev))
+            assert hashlib.md5(rec_gpu[s].tobytes()).hexdigest() == hashlib.md5(ref_cpu[s].tobytes()).hexdigest(), (s, t)
+    assert enc.poc == T - 1

@@ -9,7 +9,7 @@ from .api import (LIB_PATH, MAX_SAD, MODE_INVALID, MV_DTYPE, SLICE_B, SLICE_I, S
                   chroma_qp, dequant_plane, init, load_library, me_fullsearch, me_workspace_bytes, mv_to_numpy, quant_plane,
                   sad_blocks, tq_forward, tq_inverse, tq_roundtrip)
 
-from .pipeline import MeTqPipeline  # noqa: F401,E402
+from .pipeline import ClosedLoopGop, MeTqPipeline  # noqa: F401,E402
 from .sharding import Shard, shard_frames  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -40,6 +40,7 @@ class TqDesc(C.Structure):
         ("d_coef", C.c_void_p),
         ("d_abs_sum", C.c_void_p), ("abs_sum_frame_stride", C.c_int64),
         ("d_rec", C.c_void_p), ("rec_stride", C.c_int32), ("rec_frame_stride", C.c_int64),
+        ("mv_shift", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -213,7 +214,7 @@ def mv_to_numpy(mv):
 # xSubDct + xQuant / xDeQuant + xIDctAdd (inc/x265.h:295-298)
 # --------------------------------------------------------------------------
 def _tq_desc(tu, qp, slice_type, src=None, pred=None, mv=None, mv_ctu=64, modes=None, level=None, coef=None,
-             abs_sum=None, rec=None, pred_origin=(0, 0)):
+             abs_sum=None, rec=None, pred_origin=(0, 0), mv_shift=0):
     d = TqDesc()
     geom = None
     if src is not None:
@@ -241,6 +242,7 @@ def _tq_desc(tu, qp, slice_type, src=None, pred=None, mv=None, mv_ctu=64, modes=
         if mv.numel() != f * nctu * 2 or not mv.is_contiguous():
             raise ValueError("mv: need contiguous int32 [F][nctu][2]")
         d.d_mv, d.mv_ctu, d.mv_frame_stride = mv.data_ptr(), mv_ctu, nctu
+        d.mv_shift = mv_shift
     if modes is not None:
         _dev(modes, torch.uint8, "modes")
         ntu = (h // tu) * (w // tu)
@@ -271,28 +273,29 @@ def _alloc_like(src, dtype, tu=None):
 
 
 def tq_forward(src, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, want_coef=False,
-               pred_origin=(0, 0)):
+               pred_origin=(0, 0), mv_shift=0):
     """xSubDct + xQuant over whole planes.  Returns (level, abs_sum[, coef])."""
     level = _alloc_like(src, torch.int16)
     sums = _alloc_like(src, torch.int32, tu if tu in (4, 8, 16, 32) else 4)
     coef = _alloc_like(src, torch.int16) if want_coef else None
     d = _tq_desc(tu, qp, slice_type, src=src, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level,
-                 coef=coef, abs_sum=sums, pred_origin=pred_origin)
+                 coef=coef, abs_sum=sums, pred_origin=pred_origin, mv_shift=mv_shift)
     _check(_lib().x265amd_tq_forward(C.byref(d), _stream()), "x265amd_tq_forward")
     return (level, sums, coef) if want_coef else (level, sums)
 
 
-def tq_inverse(level, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, pred_origin=(0, 0)):
+def tq_inverse(level, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, pred_origin=(0, 0),
+               mv_shift=0):
     """xDeQuant + xIDctAdd over whole planes.  Returns rec."""
     rec = _alloc_like(level, torch.uint8)
     d = _tq_desc(tu, qp, slice_type, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level, rec=rec,
-                 pred_origin=pred_origin)
+                 pred_origin=pred_origin, mv_shift=mv_shift)
     _check(_lib().x265amd_tq_inverse(C.byref(d), _stream()), "x265amd_tq_inverse")
     return rec
 
 
 def tq_roundtrip(src, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, pred_origin=(0, 0),
-                 out=None):
+                 out=None, mv_shift=0):
     """Fused forward + inverse (src/encode.cpp:863-925).  Returns (level, abs_sum, rec).
     `out` = (level, abs_sum, rec) preallocated tensors to reuse (no allocation in the call)."""
     if out is None:
@@ -302,7 +305,7 @@ def tq_roundtrip(src, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, mode
     else:
         level, sums, rec = out
     d = _tq_desc(tu, qp, slice_type, src=src, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level,
-                 abs_sum=sums, rec=rec, pred_origin=pred_origin)
+                 abs_sum=sums, rec=rec, pred_origin=pred_origin, mv_shift=mv_shift)
     _check(_lib().x265amd_tq_roundtrip(C.byref(d), _stream()), "x265amd_tq_roundtrip")
     return level, sums, rec
 

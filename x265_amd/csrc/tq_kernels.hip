@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
                 const int xh = x0 + 16 * h;
                 if (xh < d.width) {
                     const x265amd_mv m = mvf[(y / d.mv_ctu) * ctus_x + xh / d.mv_ctu];
-                    const uint8_t *q = pp + (int64_t)(y + m.mvy) * d.pred_stride + xh + m.mvx;
+                    const uint8_t *q = pp + (int64_t)(y + (m.mvy >> d.mv_shift)) * d.pred_stride + xh + (m.mvx >> d.mv_shift);
                     if (xh + 16 <= d.width) {
                         U128 a = *reinterpret_cast<const U128 *>(q);
 #pragma unroll
@@ -351,6 +351,7 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     if (d.d_mv && (d.mv_ctu < 16 || (d.mv_ctu & (d.mv_ctu - 1)) || d.width % d.mv_ctu || d.height % d.mv_ctu ||
                    d.mv_ctu % d.tu))
         return X265AMD_ERR_ARG;
+    if (d.mv_shift < 0 || d.mv_shift > 3) return X265AMD_ERR_ARG;
     if (d.nframes == 0) return X265AMD_OK;
 
     TqParams p;

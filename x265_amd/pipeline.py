@@ -77,3 +77,90 @@ class MeTqPipeline:
     def step(self):
         self.motion_search()
         self.transform_quant()
+
+
+class ClosedLoopGop:
+    """Closed-loop P pictures: every picture is searched against, and predicted
+    from, the RECONSTRUCTION of the picture before it, with the frame / reference bookkeeping of
+    xEncEncode (src/encode.cpp:619-621, 965-970): a ring `refn[0..MAX_REF_NUM]`, the new reconstruction
+    is written into refn[MAX_REF_NUM], then the ring rotates so that refn[0] is the newest.
+
+    Time is serial inside a GOP segment, so the batch dimension is SEGMENTS: picture t of all `nseg`
+    independent segments goes down in one launch per kernel (search, luma TQ, U TQ, V TQ).  Nothing is
+    allocated and nothing synchronises after construction.
+
+    Pictures are the reference's frame layout (src/encode.cpp:41-45): one W*H*3/2 block, Y then U then V,
+    stride = width.  Luma: 64x64 CTU search, 32x32 TUs.  Chroma (4:2:0): the luma vector >> 1
+    (integer-pel; the build's own definition -- the reference has no inter prediction), 32x32 blocks,
+    16x16 TUs at g_aucChromaScale[qp] (src/encode.cpp:596).  The I picture that opens a segment is the
+    host's business (intra prediction is outside the path): hand its reconstruction to set_reference().
+    """
+    MAX_REF_NUM = 1  # inc/config.h
+
+    def __init__(self, width, height, nseg, ctu=64, search_range=64, qp=32, device="cuda", method="sea"):
+        if width % 64 or height % 64 or ctu != 64:
+            raise ValueError("width and height must be multiples of the 64x64 CTU")
+        self.w, self.h, self.nseg, self.ctu, self.range, self.qp = width, height, nseg, ctu, search_range, qp
+        self.qpc = api.chroma_qp(qp)
+        self.ysz, self.csz = width * height, (width // 2) * (height // 2)
+        self.fsz = self.ysz + 2 * self.csz
+        self.nctu = (height // ctu) * (width // ctu)
+        dev = torch.device(device)
+        self.refn = [torch.zeros((nseg, self.fsz), dtype=torch.uint8, device=dev) for _ in range(self.MAX_REF_NUM + 1)]
+        self.mv = torch.empty((nseg, 1, self.nctu, 2), dtype=torch.int32, device=dev)
+        self.level = torch.empty((nseg, self.fsz), dtype=torch.int16, device=dev)   # same Y,U,V layout as the picture
+        self.cbf_y = torch.empty((nseg, (height // 32) * (width // 32)), dtype=torch.int32, device=dev)
+        self.cbf_c = [torch.empty((nseg, (height // 32) * (width // 32)), dtype=torch.int32, device=dev) for _ in range(2)]
+        self.method = method
+        self.workspace = torch.empty(max(api.me_workspace_bytes(width, height, search_range, nseg, 1), 16),
+                                     dtype=torch.uint8, device=dev)
+        self.poc = -1  # h->iPoc, src/encode.cpp:624
+
+    def planes(self, buf):
+        """[S][W*H*3/2] picture (or level) buffer -> (Y [S][H][W], U, V [S][H/2][W/2]) views."""
+        s, w, h = buf.shape[0], self.w, self.h
+        y = buf[:, :self.ysz].unflatten(1, (h, w))
+        u = buf[:, self.ysz:self.ysz + self.csz].unflatten(1, (h // 2, w // 2))
+        v = buf[:, self.ysz + self.csz:].unflatten(1, (h // 2, w // 2))
+        return y, u, v
+
+    def _rotate(self):  # src/encode.cpp:965-970
+        tmp = self.refn[self.MAX_REF_NUM]
+        for i in range(self.MAX_REF_NUM, 0, -1):
+            self.refn[i] = self.refn[i - 1]
+        self.refn[0] = tmp
+
+    def set_reference(self, rec_yuv):
+        """The reconstruction of the segment's I picture (uint8 [S][W*H*3/2] on the GPU), made by the host."""
+        self.refn[self.MAX_REF_NUM].copy_(rec_yuv)
+        self.poc += 1
+        self._rotate()
+
+    def encode_p(self, src_yuv):
+        """One P picture per segment.  src_yuv: uint8 [S][W*H*3/2] on the GPU.  Leaves vectors in .mv,
+        levels in .level, per-TU sum|level| in .cbf_y / .cbf_c, the reconstruction in refn[0]."""
+        if src_yuv.shape != (self.nseg, self.fsz) or src_yuv.dtype != torch.uint8 or not src_yuv.is_cuda:
+            raise TypeError("src_yuv: uint8 CUDA tensor [nseg][W*H*3/2]")
+        self.poc += 1
+        sy, su, sv = self.planes(src_yuv)
+        py, pu, pv = self.planes(self.refn[0])
+        ry, ru, rv = self.planes(self.refn[self.MAX_REF_NUM])
+        ly, lu, lv = self.planes(self.level)
+        lib = api._lib()
+        args = (sy.data_ptr(), py.data_ptr(), self.w, self.h, self.w, self.ctu, self.range, self.nseg,
+                self.fsz, self.fsz, 1, 0, self.mv.data_ptr())
+        if self.method == "sea":
+            st = lib.x265amd_me_fullsearch_sea(*args, self.workspace.data_ptr(), self.workspace.numel(), api._stream())
+            if st == -5:  # X265AMD_ERR_LDS
+                self.method = "brute"
+            else:
+                api._check(st, "x265amd_me_fullsearch_sea")
+        if self.method != "sea":
+            api._check(lib.x265amd_me_fullsearch(*args, api._stream()), "x265amd_me_fullsearch")
+        mv = self.mv.view(self.nseg, self.nctu, 2)
+        api.tq_roundtrip(sy, py, 32, self.qp, api.SLICE_P, mv=mv, mv_ctu=self.ctu, out=(ly, self.cbf_y, ry))
+        for s_, p_, l_, r_, c_ in ((su, pu, lu, ru, self.cbf_c[0]), (sv, pv, lv, rv, self.cbf_c[1])):
+            api.tq_roundtrip(s_, p_, 16, self.qpc, api.SLICE_P, mv=mv, mv_ctu=self.ctu // 2, mv_shift=1,
+                             out=(l_, c_, r_))
+        self._rotate()
+        return self.refn[0]
