@@ -104,6 +104,112 @@ template <int N> __device__ __forceinline__ void inv_butterfly(const int *y, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packed variants: two Int16 operands per register, v_dot2c_i32_i16 (two multiply-adds per
+// instruction, the coefficient pair as its 32-bit literal), v_pk_add/sub_i16 with op_sel doing the
+// butterfly's mirror.  Exact as long as every dot2 operand fits Int16 -- stated at each use.
+// ---------------------------------------------------------------------------------------------
+typedef short v2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s swap2(v2s a) { return v2s{a.y, a.x}; }
+__device__ __forceinline__ int dot2(v2s a, v2s b, int c) { return __builtin_amdgcn_sdot2(a, b, c, false); }
+__device__ __forceinline__ v2s pack2(int lo, int hi) { return v2s{(short)lo, (short)hi}; }  // truncating
+
+// sum_{m < M} dot2(v[m], (T_N[R][2m], T_N[R][2m+1]))
+template <int N, int R, int... M>
+__device__ __forceinline__ int dot_row_pk(const v2s *v, int acc, std::integer_sequence<int, M...>)
+{
+    ((acc = dot2(v[M], v2s{(short)Coef<N, R, 2 * M>::value, (short)Coef<N, R, 2 * M + 1>::value}, acc)), ...);
+    return acc;
+}
+template <int N, int... K>
+__device__ __forceinline__ void fwd_odd_pk(const v2s *o, int *y, int rnd, std::integer_sequence<int, K...>)
+{
+    ((y[2 * K + 1] = dot_row_pk<N, 2 * K + 1>(o, rnd, std::make_integer_sequence<int, N / 4>{})), ...);
+}
+// y[k] = rnd + sum_j T_N[k][j] x[j];  P[m] = (x[2m], x[2m+1]), m < N/2.  Operands grow one bit per
+// level: |x| <= 2^(15 - log2 N) keeps every level inside Int16 (residuals: |x| <= 255, N <= 32: fine).
+template <int N> __device__ __forceinline__ void fwd_butterfly_pk(const v2s *P, int *y, int rnd)
+{
+    if constexpr (N == 2) {
+        y[0] = dot2(P[0], v2s{64, 64}, rnd);
+        y[1] = dot2(P[0], v2s{64, -64}, rnd);
+    } else {
+        v2s E[N / 4], O[N / 4];
+        int ye[N / 2];
+#pragma unroll
+        for (int m = 0; m < N / 4; m++) {
+            const v2s sw = swap2(P[N / 2 - 1 - m]);  // (x[N-1-2m], x[N-2-2m])
+            E[m] = P[m] + sw;
+            O[m] = P[m] - sw;
+        }
+        fwd_butterfly_pk<N / 2>(E, ye, rnd);
+#pragma unroll
+        for (int k = 0; k < N / 2; k++) y[2 * k] = ye[k];
+        fwd_odd_pk<N>(O, y, rnd, std::make_integer_sequence<int, N / 2>{});
+    }
+}
+
+// sum_{m < M} dot2((y[4m+1], y[4m+3]), (T_N[4m+1][C], T_N[4m+3][C]))   (odd rows, column C)
+template <int N, int C, int... M>
+__device__ __forceinline__ int dot_col_odd_pk(const v2s *yo, std::integer_sequence<int, M...>)
+{
+    int acc = 0;
+    ((acc = dot2(yo[M], v2s{(short)Coef<N, 4 * M + 1, C>::value, (short)Coef<N, 4 * M + 3, C>::value}, acc)), ...);
+    return acc;
+}
+template <int N, int... C>
+__device__ __forceinline__ void inv_odd_pk(const v2s *yo, int *o, std::integer_sequence<int, C...>)
+{
+    ((o[C] = dot_col_odd_pk<N, C>(yo, std::make_integer_sequence<int, N / 4>{})), ...);
+}
+// x[j] = rnd + sum_k T_N[k][j] y[k]; y[] are Int16 values held in ints (every dot2 operand is a raw
+// input, so any Int16 input is exact).  S = index stride of this level's inputs in y[].
+template <int N, int S = 1> __device__ __forceinline__ void inv_butterfly_pk(const int *y, int *x, int rnd)
+{
+    if constexpr (N == 2) {
+        const v2s p = pack2(y[0], y[S]);
+        x[0] = dot2(p, v2s{64, 64}, rnd);
+        x[1] = dot2(p, v2s{64, -64}, rnd);
+    } else {
+        int e[N / 2], o[N / 2];
+        v2s yo[N / 4];
+#pragma unroll
+        for (int m = 0; m < N / 4; m++) yo[m] = pack2(y[(4 * m + 1) * S], y[(4 * m + 3) * S]);
+        inv_butterfly_pk<N / 2, 2 * S>(y, e, rnd);
+        inv_odd_pk<N>(yo, o, std::make_integer_sequence<int, N / 2>{});
+#pragma unroll
+        for (int j = 0; j < N / 2; j++) {
+            x[j] = e[j] + o[j];
+            x[N - 1 - j] = e[j] - o[j];
+        }
+    }
+}
+
+// Forward transform of FULL-RANGE Int16 inputs (the column pass: x[k] - x[N-1-k] needs 17 bits).
+// Q[k] = (x[k], x[N-1-k]): the odd rows take dot2(Q[k], (T, -T)) -- raw operands, exact -- and the even
+// half goes on in 32 bits through the scalar butterfly.
+template <int N, int R, int... K>
+__device__ __forceinline__ int dot_row_mirror(const v2s *Q, int acc, std::integer_sequence<int, K...>)
+{
+    ((acc = dot2(Q[K], v2s{(short)Coef<N, R, K>::value, (short)(-Coef<N, R, K>::value)}, acc)), ...);
+    return acc;
+}
+template <int N, int... K>
+__device__ __forceinline__ void fwd_odd_mirror(const v2s *Q, int *y, int rnd, std::integer_sequence<int, K...>)
+{
+    ((y[2 * K + 1] = dot_row_mirror<N, 2 * K + 1>(Q, rnd, std::make_integer_sequence<int, N / 2>{})), ...);
+}
+template <int N> __device__ __forceinline__ void fwd_butterfly_wide(const v2s *Q, int *y, int rnd)
+{
+    int e[N / 2], ye[N / 2];
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) e[k] = (int)Q[k].x + (int)Q[k].y;
+    fwd_butterfly<N / 2>(e, ye);
+#pragma unroll
+    for (int k = 0; k < N / 2; k++) y[2 * k] = ye[k] + rnd;
+    fwd_odd_mirror<N>(Q, y, rnd, std::make_integer_sequence<int, N / 2>{});
+}
+
 // 4-point DST-VII (xDST4 src/pixel.cpp:133-151; xInvDST4 :346-369), matrix
 // {29,55,74,84; 74,74,0,-74; 84,-29,-74,55; 55,-84,74,-29}
 __device__ __forceinline__ void fwd_dst4(const int *x, int *y)

@@ -43,6 +43,14 @@ enum { TQ_FWD = 1, TQ_INV = 2, TQ_BOTH = 3 };
 
 constexpr int kPitch = 34;  // Int16 elements per LDS row: 17 dwords (odd) => conflict-free both ways
 
+__device__ __forceinline__ v2s as_v2s(uint32_t u) { return __builtin_bit_cast(v2s, u); }
+__device__ __forceinline__ uint32_t as_u32(v2s v) { return __builtin_bit_cast(uint32_t, v); }
+// bytes (2h, 2h+1) of a dword as two u16 lanes (v_perm_b32; selector 0x0c = constant zero)
+__device__ __forceinline__ v2s byte_pair(uint32_t w, int h)
+{
+    return as_v2s(__builtin_amdgcn_perm(0u, w, h ? 0x0c030c02u : 0x0c010c00u));
+}
+
 __device__ __forceinline__ int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 __device__ __forceinline__ int wrap16(int v) { return (int)(short)v; }
 
@@ -127,44 +135,58 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
 
     if constexpr (MODE & TQ_FWD) {
         // ================= pass 1: residual + horizontal transform =================
-        int res[32];
-        {
-            uint32_t srcw[8];
+        uint32_t srcw[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) srcw[i] = 0;
-            if (row_ok)
-                load_row32(d.d_src + (int64_t)f * d.src_frame_stride + (int64_t)(y0 + ln) * d.src_stride + x0,
-                           full_w, wvalid, srcw);
+        for (int i = 0; i < 8; i++) srcw[i] = 0;
+        if (row_ok)
+            load_row32(d.d_src + (int64_t)f * d.src_frame_stride + (int64_t)(y0 + ln) * d.src_stride + x0, full_w,
+                       wvalid, srcw);
+        constexpr int sh1 = L2 - 1, rnd1 = 1 << (sh1 - 1);
+        if constexpr (N >= 8) {
+            // packed: residual pairs (|r| <= 255), butterflies in Int16 lanes, two MACs per v_dot2c
+            v2s P[16];
+#pragma unroll
+            for (int m = 0; m < 16; m++) P[m] = byte_pair(srcw[m >> 1], m & 1) - byte_pair(predw[m >> 1], m & 1);
+#pragma unroll
+            for (int s = 0; s < NSEG; s++) {
+                int yv[N];
+                fwd_butterfly_pk<N>(&P[s * (N / 2)], yv, rnd1);
+#pragma unroll
+                for (int k = 0; k < N; k += 2)  // truncating Int16 stores
+                    *reinterpret_cast<v2s *>(&T[ln][s * N + k]) = pack2(yv[k] >> sh1, yv[k + 1] >> sh1);
+            }
+        } else {
+            int res[32];
 #pragma unroll
             for (int i = 0; i < 32; i++)
                 res[i] = (int)((srcw[i >> 2] >> (8 * (i & 3))) & 255u) - (int)((predw[i >> 2] >> (8 * (i & 3))) & 255u);
-        }
-        constexpr int sh1 = L2 - 1, rnd1 = 1 << (sh1 - 1);
 #pragma unroll
-        for (int s = 0; s < NSEG; s++) {
-            int yv[N];
-            bool dst = false;
-            if constexpr (N == 4) {
+            for (int s = 0; s < NSEG; s++) {
+                int yv[N];
+                bool dst = false;
                 if (d.d_modes && row_ok && s * 4 < wvalid)
                     dst = use_dst(4, d.d_modes[(int64_t)f * d.modes_frame_stride + ((y0 + ln) >> 2) * tus_x + (x0 >> 2) + s], true);
-            }
-            if (N == 4 && dst)
-                fwd_dst4(&res[s * N], yv);
-            else
-                fwd_butterfly<N>(&res[s * N], yv);
+                if (dst)
+                    fwd_dst4(&res[s * N], yv);
+                else
+                    fwd_butterfly<N>(&res[s * N], yv);
 #pragma unroll
-            for (int k = 0; k < N; k += 2) {
-                const int a = (yv[k] + rnd1) >> sh1, b = (yv[k + 1] + rnd1) >> sh1;  // truncating Int16 stores
-                *reinterpret_cast<uint32_t *>(&T[ln][s * N + k]) = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+                for (int k = 0; k < N; k += 2) {
+                    const int a = (yv[k] + rnd1) >> sh1, b = (yv[k + 1] + rnd1) >> sh1;  // truncating Int16 stores
+                    *reinterpret_cast<uint32_t *>(&T[ln][s * N + k]) = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+                }
             }
         }
         __syncthreads();
 
         // ================= pass 2: vertical transform + quantisation =================
         const bool col_ok = tile_ok && ln < wvalid;
-        int v[32];
+        // the lane's column, as mirror pairs (x[k], x[N-1-k]) per segment
+        v2s Q[16];
 #pragma unroll
-        for (int i = 0; i < 32; i++) v[i] = T[i][ln];
+        for (int s = 0; s < NSEG; s++)
+#pragma unroll
+            for (int k = 0; k < N / 2; k++) Q[s * (N / 2) + k] = v2s{T[s * N + k][ln], T[s * N + N - 1 - k][ln]};
         __syncthreads();  // the inverse reuses the tile buffer
 
         constexpr int sh2 = L2 + 6, rnd2 = 1 << (sh2 - 1);
@@ -172,27 +194,38 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
         int16_t *cfp = d.d_coef ? d.d_coef + (int64_t)f * d.level_frame_stride + (int64_t)y0 * d.level_stride + x0 + ln : nullptr;
 #pragma unroll
         for (int s = 0; s < NSEG; s++) {
-            int yv[N];
-            bool dst = false;
-            if constexpr (N == 4) {
+            int yv[N];  // includes the rounding offset when N >= 8
+            if constexpr (N >= 8) {
+                fwd_butterfly_wide<N>(&Q[s * (N / 2)], yv, rnd2);
+            } else {
+                int v[N];
+#pragma unroll
+                for (int k = 0; k < N / 2; k++) {
+                    v[k] = Q[s * (N / 2) + k].x;
+                    v[N - 1 - k] = Q[s * (N / 2) + k].y;
+                }
+                bool dst = false;
                 if (d.d_modes && col_ok && s * 4 < hvalid)
                     dst = use_dst(4, d.d_modes[(int64_t)f * d.modes_frame_stride + ((y0 >> 2) + s) * tus_x + ((x0 + ln) >> 2)], false);
+                if (dst)
+                    fwd_dst4(v, yv);
+                else
+                    fwd_butterfly<N>(v, yv);
+#pragma unroll
+                for (int m = 0; m < N; m++) yv[m] += rnd2;
             }
-            if (N == 4 && dst)
-                fwd_dst4(&v[s * N], yv);
-            else
-                fwd_butterfly<N>(&v[s * N], yv);
             unsigned sum = 0;
             const bool seg_ok = col_ok && s * N < hvalid;
 #pragma unroll
             for (int m = 0; m < N; m++) {
-                const int c = wrap16((yv[m] + rnd2) >> sh2);
+                const int c = wrap16(yv[m] >> sh2);
                 if (cfp && seg_ok) cfp[(int64_t)(s * N + m) * d.level_stride] = (int16_t)c;
                 // xQuant, src/pixel.cpp:609-616: unsigned 32-bit multiply-add, logical shift
-                const unsigned a = (unsigned)(c < 0 ? -c : c);
+                const int sg = c >> 31;  // 0 / -1
+                const unsigned a = (unsigned)((c ^ sg) - sg);
                 const unsigned lv = (__umul24(a, p.q_scale) + p.q_rnd) >> p.q_bits;
                 sum += lv;
-                const int sl = c < 0 ? -(int)lv : (int)lv;
+                const int sl = ((int)lv ^ sg) - sg;
                 lvl[s * N + m] = (int16_t)sl;
                 if (seg_ok) lvp[(int64_t)(s * N + m) * d.level_stride] = (int16_t)sl;
             }
@@ -225,15 +258,19 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
                 if (d.d_modes && col_ok && s * 4 < hvalid)
                     dst = use_dst(4, d.d_modes[(int64_t)f * d.modes_frame_stride + ((y0 >> 2) + s) * tus_x + ((x0 + ln) >> 2)], false);
             }
-            if (N == 4 && dst)
-                inv_dst4(in, xv);
-            else
-                inv_butterfly<N>(in, xv);
+            if constexpr (N >= 8) {
+                inv_butterfly_pk<N>(in, xv, 64);  // every dot2 operand is a clipped Int16 coefficient
+            } else {
+                if (dst)
+                    inv_dst4(in, xv);
+                else
+                    inv_butterfly<N>(in, xv);
 #pragma unroll
-            for (int k = 0; k < N; k += 2) {  // SHIFT_INV_1ST = 7; store-then-clip => wraps (src/pixel.cpp:334-342)
-                const int a = (xv[k] + 64) >> 7, b = (xv[k + 1] + 64) >> 7;
-                *reinterpret_cast<uint32_t *>(&T[ln][s * N + k]) = ((uint32_t)a & 0xffffu) | ((uint32_t)b << 16);
+                for (int k = 0; k < N; k++) xv[k] += 64;
             }
+#pragma unroll
+            for (int k = 0; k < N; k += 2)  // SHIFT_INV_1ST = 7; store-then-clip => wraps (src/pixel.cpp:334-342)
+                *reinterpret_cast<v2s *>(&T[ln][s * N + k]) = pack2(xv[k] >> 7, xv[k + 1] >> 7);
         }
         __syncthreads();
 
@@ -252,16 +289,31 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
                 if (d.d_modes && row_ok && s * 4 < wvalid)
                     dst = use_dst(4, d.d_modes[(int64_t)f * d.modes_frame_stride + ((y0 + ln) >> 2) * tus_x + (x0 >> 2) + s], true);
             }
-            if (N == 4 && dst)
-                inv_dst4(&v[s * N], xv);
-            else
-                inv_butterfly<N>(&v[s * N], xv);
+            if constexpr (N >= 8) {
+                inv_butterfly_pk<N>(&v[s * N], xv, 2048);  // operands: the Int16 intermediate, raw
+                // SHIFT_INV_2ND = 12, wrap (the pack truncates), then Clip(res + pred) (src/pixel.cpp:759) on
+                // Int16 pairs: the saturating add cannot change a sum that is clipped to 0..255 anyway
 #pragma unroll
-            for (int k = 0; k < N; k++) {  // SHIFT_INV_2ND = 12, wrap, then Clip(res + pred) (src/pixel.cpp:759)
-                const int i = s * N + k;
-                const int r = wrap16((xv[k] + 2048) >> 12) + (int)((predw[i >> 2] >> (8 * (i & 3))) & 255u);
-                const unsigned c = (unsigned)(r < 0 ? 0 : (r > 255 ? 255 : r));
-                recw[i >> 2] |= c << (8 * (i & 3));
+                for (int k = 0; k < N; k += 4) {
+                    const int i = s * N + k;
+                    v2s r0 = __builtin_elementwise_add_sat(pack2(xv[k] >> 12, xv[k + 1] >> 12), byte_pair(predw[i >> 2], 0));
+                    v2s r1 = __builtin_elementwise_add_sat(pack2(xv[k + 2] >> 12, xv[k + 3] >> 12), byte_pair(predw[i >> 2], 1));
+                    r0 = __builtin_elementwise_min(__builtin_elementwise_max(r0, v2s{0, 0}), v2s{255, 255});
+                    r1 = __builtin_elementwise_min(__builtin_elementwise_max(r1, v2s{0, 0}), v2s{255, 255});
+                    recw[i >> 2] = __builtin_amdgcn_perm(as_u32(r1), as_u32(r0), 0x06040200u);
+                }
+            } else {
+                if (dst)
+                    inv_dst4(&v[s * N], xv);
+                else
+                    inv_butterfly<N>(&v[s * N], xv);
+#pragma unroll
+                for (int k = 0; k < N; k++) {  // SHIFT_INV_2ND = 12, wrap, then Clip(res + pred) (src/pixel.cpp:759)
+                    const int i = s * N + k;
+                    const int r = wrap16((xv[k] + 2048) >> 12) + (int)((predw[i >> 2] >> (8 * (i & 3))) & 255u);
+                    const unsigned c = (unsigned)(r < 0 ? 0 : (r > 255 ? 255 : r));
+                    recw[i >> 2] |= c << (8 * (i & 3));
+                }
             }
         }
         if (row_ok) {
