@@ -114,25 +114,31 @@ __device__ __forceinline__ v2s swap2(v2s a) { return v2s{a.y, a.x}; }
 __device__ __forceinline__ int dot2(v2s a, v2s b, int c) { return __builtin_amdgcn_sdot2(a, b, c, false); }
 __device__ __forceinline__ v2s pack2(int lo, int hi) { return v2s{(short)lo, (short)hi}; }  // truncating
 
+// Every packed transform takes SC: all coefficients are multiplied by 2^SC, so the result is
+// 2^SC * (rnd + sum) modulo 2^32.  The callers only ever keep 16 bits [sh+15 : sh] of the sum; with
+// SC chosen so that sh + SC is 8 or 16 those bits sit on a byte boundary and one v_perm_b32 packs two
+// results -- no shift instructions.  Wrapping modulo 2^32 cannot disturb bits below 32.
+
 // sum_{m < M} dot2(v[m], (T_N[R][2m], T_N[R][2m+1]))
-template <int N, int R, int... M>
+template <int N, int SC, int R, int... M>
 __device__ __forceinline__ int dot_row_pk(const v2s *v, int acc, std::integer_sequence<int, M...>)
 {
-    ((acc = dot2(v[M], v2s{(short)Coef<N, R, 2 * M>::value, (short)Coef<N, R, 2 * M + 1>::value}, acc)), ...);
+    ((acc = dot2(v[M], v2s{(short)(Coef<N, R, 2 * M>::value * (1 << SC)), (short)(Coef<N, R, 2 * M + 1>::value * (1 << SC))}, acc)), ...);
     return acc;
 }
-template <int N, int... K>
+template <int N, int SC, int... K>
 __device__ __forceinline__ void fwd_odd_pk(const v2s *o, int *y, int rnd, std::integer_sequence<int, K...>)
 {
-    ((y[2 * K + 1] = dot_row_pk<N, 2 * K + 1>(o, rnd, std::make_integer_sequence<int, N / 4>{})), ...);
+    ((y[2 * K + 1] = dot_row_pk<N, SC, 2 * K + 1>(o, rnd, std::make_integer_sequence<int, N / 4>{})), ...);
 }
-// y[k] = rnd + sum_j T_N[k][j] x[j];  P[m] = (x[2m], x[2m+1]), m < N/2.  Operands grow one bit per
+// y[k] = rnd + 2^SC sum_j T_N[k][j] x[j];  P[m] = (x[2m], x[2m+1]), m < N/2.  Operands grow one bit per
 // level: |x| <= 2^(15 - log2 N) keeps every level inside Int16 (residuals: |x| <= 255, N <= 32: fine).
-template <int N> __device__ __forceinline__ void fwd_butterfly_pk(const v2s *P, int *y, int rnd)
+template <int N, int SC> __device__ __forceinline__ void fwd_butterfly_pk(const v2s *P, int *y, int rnd)
 {
+    static_assert((90 << SC) < 32768, "scaled coefficient must fit Int16");
     if constexpr (N == 2) {
-        y[0] = dot2(P[0], v2s{64, 64}, rnd);
-        y[1] = dot2(P[0], v2s{64, -64}, rnd);
+        y[0] = dot2(P[0], v2s{(short)(64 << SC), (short)(64 << SC)}, rnd);
+        y[1] = dot2(P[0], v2s{(short)(64 << SC), (short)(-(64 << SC))}, rnd);
     } else {
         v2s E[N / 4], O[N / 4];
         int ye[N / 2];
@@ -142,41 +148,42 @@ template <int N> __device__ __forceinline__ void fwd_butterfly_pk(const v2s *P, 
             E[m] = P[m] + sw;
             O[m] = P[m] - sw;
         }
-        fwd_butterfly_pk<N / 2>(E, ye, rnd);
+        fwd_butterfly_pk<N / 2, SC>(E, ye, rnd);
 #pragma unroll
         for (int k = 0; k < N / 2; k++) y[2 * k] = ye[k];
-        fwd_odd_pk<N>(O, y, rnd, std::make_integer_sequence<int, N / 2>{});
+        fwd_odd_pk<N, SC>(O, y, rnd, std::make_integer_sequence<int, N / 2>{});
     }
 }
 
 // sum_{m < M} dot2((y[4m+1], y[4m+3]), (T_N[4m+1][C], T_N[4m+3][C]))   (odd rows, column C)
-template <int N, int C, int... M>
+template <int N, int SC, int C, int... M>
 __device__ __forceinline__ int dot_col_odd_pk(const v2s *yo, std::integer_sequence<int, M...>)
 {
     int acc = 0;
-    ((acc = dot2(yo[M], v2s{(short)Coef<N, 4 * M + 1, C>::value, (short)Coef<N, 4 * M + 3, C>::value}, acc)), ...);
+    ((acc = dot2(yo[M], v2s{(short)(Coef<N, 4 * M + 1, C>::value * (1 << SC)), (short)(Coef<N, 4 * M + 3, C>::value * (1 << SC))}, acc)), ...);
     return acc;
 }
-template <int N, int... C>
+template <int N, int SC, int... C>
 __device__ __forceinline__ void inv_odd_pk(const v2s *yo, int *o, std::integer_sequence<int, C...>)
 {
-    ((o[C] = dot_col_odd_pk<N, C>(yo, std::make_integer_sequence<int, N / 4>{})), ...);
+    ((o[C] = dot_col_odd_pk<N, SC, C>(yo, std::make_integer_sequence<int, N / 4>{})), ...);
 }
-// x[j] = rnd + sum_k T_N[k][j] y[k]; y[] are Int16 values held in ints (every dot2 operand is a raw
-// input, so any Int16 input is exact).  S = index stride of this level's inputs in y[].
-template <int N, int S = 1> __device__ __forceinline__ void inv_butterfly_pk(const int *y, int *x, int rnd)
+// x[j] = rnd + 2^SC sum_k T_N[k][j] y[k]; y[] are Int16 values held in ints (every dot2 operand is a
+// raw input, so any Int16 input is exact).  S = index stride of this level's inputs in y[].
+template <int N, int SC, int S = 1> __device__ __forceinline__ void inv_butterfly_pk(const int *y, int *x, int rnd)
 {
+    static_assert((90 << SC) < 32768, "scaled coefficient must fit Int16");
     if constexpr (N == 2) {
         const v2s p = pack2(y[0], y[S]);
-        x[0] = dot2(p, v2s{64, 64}, rnd);
-        x[1] = dot2(p, v2s{64, -64}, rnd);
+        x[0] = dot2(p, v2s{(short)(64 << SC), (short)(64 << SC)}, rnd);
+        x[1] = dot2(p, v2s{(short)(64 << SC), (short)(-(64 << SC))}, rnd);
     } else {
         int e[N / 2], o[N / 2];
         v2s yo[N / 4];
 #pragma unroll
         for (int m = 0; m < N / 4; m++) yo[m] = pack2(y[(4 * m + 1) * S], y[(4 * m + 3) * S]);
-        inv_butterfly_pk<N / 2, 2 * S>(y, e, rnd);
-        inv_odd_pk<N>(yo, o, std::make_integer_sequence<int, N / 2>{});
+        inv_butterfly_pk<N / 2, SC, 2 * S>(y, e, rnd);
+        inv_odd_pk<N, SC>(yo, o, std::make_integer_sequence<int, N / 2>{});
 #pragma unroll
         for (int j = 0; j < N / 2; j++) {
             x[j] = e[j] + o[j];
@@ -187,27 +194,28 @@ template <int N, int S = 1> __device__ __forceinline__ void inv_butterfly_pk(con
 
 // Forward transform of FULL-RANGE Int16 inputs (the column pass: x[k] - x[N-1-k] needs 17 bits).
 // Q[k] = (x[k], x[N-1-k]): the odd rows take dot2(Q[k], (T, -T)) -- raw operands, exact -- and the even
-// half goes on in 32 bits through the scalar butterfly.
-template <int N, int R, int... K>
+// half goes on in 32 bits through the scalar butterfly (scaled afterwards: one v_lshl_add with rnd).
+template <int N, int SC, int R, int... K>
 __device__ __forceinline__ int dot_row_mirror(const v2s *Q, int acc, std::integer_sequence<int, K...>)
 {
-    ((acc = dot2(Q[K], v2s{(short)Coef<N, R, K>::value, (short)(-Coef<N, R, K>::value)}, acc)), ...);
+    ((acc = dot2(Q[K], v2s{(short)(Coef<N, R, K>::value * (1 << SC)), (short)(-(Coef<N, R, K>::value * (1 << SC)))}, acc)), ...);
     return acc;
 }
-template <int N, int... K>
+template <int N, int SC, int... K>
 __device__ __forceinline__ void fwd_odd_mirror(const v2s *Q, int *y, int rnd, std::integer_sequence<int, K...>)
 {
-    ((y[2 * K + 1] = dot_row_mirror<N, 2 * K + 1>(Q, rnd, std::make_integer_sequence<int, N / 2>{})), ...);
+    ((y[2 * K + 1] = dot_row_mirror<N, SC, 2 * K + 1>(Q, rnd, std::make_integer_sequence<int, N / 2>{})), ...);
 }
-template <int N> __device__ __forceinline__ void fwd_butterfly_wide(const v2s *Q, int *y, int rnd)
+template <int N, int SC> __device__ __forceinline__ void fwd_butterfly_wide(const v2s *Q, int *y, int rnd)
 {
+    static_assert((90 << SC) < 32768, "scaled coefficient must fit Int16");
     int e[N / 2], ye[N / 2];
 #pragma unroll
     for (int k = 0; k < N / 2; k++) e[k] = (int)Q[k].x + (int)Q[k].y;
     fwd_butterfly<N / 2>(e, ye);
 #pragma unroll
-    for (int k = 0; k < N / 2; k++) y[2 * k] = ye[k] + rnd;
-    fwd_odd_mirror<N>(Q, y, rnd, std::make_integer_sequence<int, N / 2>{});
+    for (int k = 0; k < N / 2; k++) y[2 * k] = (int)(((unsigned)ye[k] << SC) + (unsigned)rnd);
+    fwd_odd_mirror<N, SC>(Q, y, rnd, std::make_integer_sequence<int, N / 2>{});
 }
 
 // 4-point DST-VII (xDST4 src/pixel.cpp:133-151; xInvDST4 :346-369), matrix

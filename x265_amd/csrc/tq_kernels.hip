@@ -51,6 +51,10 @@ __device__ __forceinline__ v2s byte_pair(uint32_t w, int h)
     return as_v2s(__builtin_amdgcn_perm(0u, w, h ? 0x0c030c02u : 0x0c010c00u));
 }
 
+// two results whose wanted 16 bits sit at [23:8] / at [31:16] -> one Int16 pair
+__device__ __forceinline__ v2s pack_mid(int a, int b) { return as_v2s(__builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x06050201u)); }
+__device__ __forceinline__ v2s pack_hi(int a, int b) { return as_v2s(__builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x07060302u)); }
+
 __device__ __forceinline__ int clip16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
 __device__ __forceinline__ int wrap16(int v) { return (int)(short)v; }
 
@@ -73,7 +77,7 @@ __device__ __forceinline__ void load_row32(const uint8_t *p, bool full, int wval
 }
 
 template <int N, int MODE>
-__global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
+__global__ __launch_bounds__(256, 4) void tq_kernel(const TqParams p)
 {
     __shared__ int16_t lds[8][32][kPitch];
     constexpr int L2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
@@ -150,10 +154,11 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
 #pragma unroll
             for (int s = 0; s < NSEG; s++) {
                 int yv[N];
-                fwd_butterfly_pk<N>(&P[s * (N / 2)], yv, rnd1);
+                constexpr int SC = 8 - sh1;  // bits [sh1+15 : sh1] of the sum land on [23:8]
+                fwd_butterfly_pk<N, SC>(&P[s * (N / 2)], yv, rnd1 << SC);
 #pragma unroll
                 for (int k = 0; k < N; k += 2)  // truncating Int16 stores
-                    *reinterpret_cast<v2s *>(&T[ln][s * N + k]) = pack2(yv[k] >> sh1, yv[k + 1] >> sh1);
+                    *reinterpret_cast<v2s *>(&T[ln][s * N + k]) = pack_mid(yv[k], yv[k + 1]);
             }
         } else {
             int res[32];
@@ -194,9 +199,10 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
         int16_t *cfp = d.d_coef ? d.d_coef + (int64_t)f * d.level_frame_stride + (int64_t)y0 * d.level_stride + x0 + ln : nullptr;
 #pragma unroll
         for (int s = 0; s < NSEG; s++) {
-            int yv[N];  // includes the rounding offset when N >= 8
+            int yv[N];  // includes the rounding offset; scaled by 2^SC2 (wanted bits at [31:16]) when N >= 8
+            constexpr int SC2 = N >= 8 ? 16 - sh2 : 0;
             if constexpr (N >= 8) {
-                fwd_butterfly_wide<N>(&Q[s * (N / 2)], yv, rnd2);
+                fwd_butterfly_wide<N, SC2>(&Q[s * (N / 2)], yv, (int)((unsigned)rnd2 << SC2));
             } else {
                 int v[N];
 #pragma unroll
@@ -218,8 +224,8 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
             const bool seg_ok = col_ok && s * N < hvalid;
 #pragma unroll
             for (int m = 0; m < N; m++) {
-                const int c = wrap16(yv[m] >> sh2);
-                if (cfp && seg_ok) cfp[(int64_t)(s * N + m) * d.level_stride] = (int16_t)c;
+                const int c = N >= 8 ? yv[m] >> 16 : wrap16(yv[m] >> sh2);
+                yv[m] = c;
                 // xQuant, src/pixel.cpp:609-616: unsigned 32-bit multiply-add, logical shift
                 const int sg = c >> 31;  // 0 / -1
                 const unsigned a = (unsigned)((c ^ sg) - sg);
@@ -227,7 +233,14 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
                 sum += lv;
                 const int sl = ((int)lv ^ sg) - sg;
                 lvl[s * N + m] = (int16_t)sl;
-                if (seg_ok) lvp[(int64_t)(s * N + m) * d.level_stride] = (int16_t)sl;
+            }
+            if (seg_ok) {  // one predicate around the column's stores
+#pragma unroll
+                for (int m = 0; m < N; m++) lvp[(int64_t)(s * N + m) * d.level_stride] = lvl[s * N + m];
+                if (cfp) {
+#pragma unroll
+                    for (int m = 0; m < N; m++) cfp[(int64_t)(s * N + m) * d.level_stride] = (int16_t)yv[m];
+                }
             }
             if (d.d_abs_sum) {
 #pragma unroll
@@ -259,18 +272,19 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
                     dst = use_dst(4, d.d_modes[(int64_t)f * d.modes_frame_stride + ((y0 >> 2) + s) * tus_x + ((x0 + ln) >> 2)], false);
             }
             if constexpr (N >= 8) {
-                inv_butterfly_pk<N>(in, xv, 64);  // every dot2 operand is a clipped Int16 coefficient
+                inv_butterfly_pk<N, 1>(in, xv, 64 << 1);  // every dot2 operand is a clipped Int16 coefficient
+#pragma unroll
+                for (int k = 0; k < N; k += 2)  // SHIFT_INV_1ST = 7 (+1: scaled); store-then-clip => wraps (src/pixel.cpp:334-342)
+                    *reinterpret_cast<v2s *>(&T[ln][s * N + k]) = pack_mid(xv[k], xv[k + 1]);
             } else {
                 if (dst)
                     inv_dst4(in, xv);
                 else
                     inv_butterfly<N>(in, xv);
 #pragma unroll
-                for (int k = 0; k < N; k++) xv[k] += 64;
+                for (int k = 0; k < N; k += 2)  // SHIFT_INV_1ST = 7; store-then-clip => wraps (src/pixel.cpp:334-342)
+                    *reinterpret_cast<v2s *>(&T[ln][s * N + k]) = pack2((xv[k] + 64) >> 7, (xv[k + 1] + 64) >> 7);
             }
-#pragma unroll
-            for (int k = 0; k < N; k += 2)  // SHIFT_INV_1ST = 7; store-then-clip => wraps (src/pixel.cpp:334-342)
-                *reinterpret_cast<v2s *>(&T[ln][s * N + k]) = pack2(xv[k] >> 7, xv[k + 1] >> 7);
         }
         __syncthreads();
 
@@ -290,14 +304,14 @@ __global__ __launch_bounds__(256) void tq_kernel(const TqParams p)
                     dst = use_dst(4, d.d_modes[(int64_t)f * d.modes_frame_stride + ((y0 + ln) >> 2) * tus_x + (x0 >> 2) + s], true);
             }
             if constexpr (N >= 8) {
-                inv_butterfly_pk<N>(&v[s * N], xv, 2048);  // operands: the Int16 intermediate, raw
-                // SHIFT_INV_2ND = 12, wrap (the pack truncates), then Clip(res + pred) (src/pixel.cpp:759) on
+                inv_butterfly_pk<N, 4>(&v[s * N], xv, 2048 << 4);  // operands: the Int16 intermediate, raw
+                // SHIFT_INV_2ND = 12 (+4: scaled, bits [31:16]), wrap (the pack truncates), then Clip(res + pred) (src/pixel.cpp:759) on
                 // Int16 pairs: the saturating add cannot change a sum that is clipped to 0..255 anyway
 #pragma unroll
                 for (int k = 0; k < N; k += 4) {
                     const int i = s * N + k;
-                    v2s r0 = __builtin_elementwise_add_sat(pack2(xv[k] >> 12, xv[k + 1] >> 12), byte_pair(predw[i >> 2], 0));
-                    v2s r1 = __builtin_elementwise_add_sat(pack2(xv[k + 2] >> 12, xv[k + 3] >> 12), byte_pair(predw[i >> 2], 1));
+                    v2s r0 = __builtin_elementwise_add_sat(pack_hi(xv[k], xv[k + 1]), byte_pair(predw[i >> 2], 0));
+                    v2s r1 = __builtin_elementwise_add_sat(pack_hi(xv[k + 2], xv[k + 3]), byte_pair(predw[i >> 2], 1));
                     r0 = __builtin_elementwise_min(__builtin_elementwise_max(r0, v2s{0, 0}), v2s{255, 255});
                     r1 = __builtin_elementwise_min(__builtin_elementwise_max(r1, v2s{0, 0}), v2s{255, 255});
                     recw[i >> 2] = __builtin_amdgcn_perm(as_u32(r1), as_u32(r0), 0x06040200u);
