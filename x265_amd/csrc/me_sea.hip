@@ -114,16 +114,18 @@ __host__ __device__ inline SeaLayout sea_layout(int w, int h, int range, int cx,
 
 constexpr int kBins = 96;         // quarter-octave bins of the bound: covers 24 octaves
 
+// Monotone bin of a stored bound: exponent and top two mantissa bits of its float image (exact for
+// lb < 2^24): v_cvt_f32_u32 + shift + subtract.  0 -> 0, 1 -> 1, 2 -> 5, 3 -> 7, 4 -> 9, ..., 65534 -> 64.
 __device__ __forceinline__ int lb_bin(uint32_t lb)
 {
-    if (lb < 4) return (int)lb;
-    const int msb = 31 - __clz((int)lb);
-    return 4 * (msb - 1) + (int)((lb >> (msb - 2)) & 3u);  // lb=4 -> 4, monotone, < 96 for lb < 2^24
+    const int e = (int)(__float_as_uint((float)lb) >> 21) - 507;
+    return e < 0 ? 0 : e;
 }
 
 constexpr int kMaxChain = 20;     // chain steps of 16 rows: ndy <= 257 (R <= 128) needs 17
 constexpr int kSeaThreads = 512;  // 8 waves (exact kernel)
 constexpr int kBoundsThreads = 512;  // 8 waves, 4 workgroups per CU
+constexpr uint32_t kIllegal = 1u << 30;  // > any bound (16 * 65280)
 constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or already scheduled
 
 // Bounds are kept as u16 = floor(LB / 16) (LB <= 16 * 65280): still a lower bound, 15 units coarser.
@@ -212,11 +214,11 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             if (c >= L.ndy) continue;
             const uint32_t *pp = P + (int64_t)(cy + L.dylo + c) * g.width + L.wx0 + 4 * gx;
             const int64_t band = (int64_t)16 * g.width;
-            uint32_t legal = 0;
+            uint32_t lb0[4];  // accumulator start: 0 for a legal member, 2^30 for one outside the picture
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int dxi = 4 * gx + q - a;
-                if (dxi >= 0 && dxi < ndx) legal |= 1u << q;
+                lb0[q] = (dxi >= 0 && dxi < ndx) ? 0u : kIllegal;
             }
             // five band registers used round-robin: while step m is being summed, band m+4 is in flight
             uint4 bnd[5][2];
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
                         for (int kp = 0; kp < 2; kp++)
                             bnd[(mm + 4) % 5][kp] = *reinterpret_cast<const uint4 *>(pp + (m + 4) * band + 32 * kp);
                     }
-                    uint32_t lb[4] = {0u, 0u, 0u, 0u};
+                    uint32_t lb[4] = {lb0[0], lb0[1], lb0[2], lb0[3]};
 #pragma unroll
                     for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -247,11 +249,8 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
                             lb[2] = __builtin_amdgcn_sad_u16(v.z, sc, lb[2]);
                             lb[3] = __builtin_amdgcn_sad_u16(v.w, sc, lb[3]);
                         }
-                    uint32_t mn = 0xffffffffu;
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        if (legal & (1u << q)) mn = min(mn, lb[q]);
-                    const uint32_t st = mn == 0xffffffffu ? kNone : lb_store(mn);
+                    const uint32_t mn = min(min(lb[0], lb[1]), min(lb[2], lb[3]));
+                    const uint32_t st = mn >= kIllegal ? kNone : lb_store(mn);
                     glb[dyi * L.ngx + gx] = (uint16_t)st;
                     if (st != kNone) atomicAdd(&hist[lb_bin(st)], 1u);
                 }
@@ -346,6 +345,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     uint32_t rest_min = kNone;
     const int nvec = (L.ngroups + 7) >> 3;
     for (int v0 = 0; v0 < nvec; v0 += kBoundsThreads) {
+        if (v0 + (tid & ~63) >= nvec) break;  // nothing left for this wave (wave-uniform; no barrier inside)
         const int vi = v0 + tid;
         uint4 wv = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
         if (vi < nvec) wv = reinterpret_cast<const uint4 *>(glb)[vi];
