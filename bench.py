@@ -42,6 +42,7 @@ WORKLOADS = {
     "1080p": (1920, 1080, 64, 64, 1, 16, 32, 32),     # BASELINE.json configs[1]
     "4k": (3840, 2160, 64, 128, 1, 4, 32, 32),        # configs[3]: one GOP segment of 4 per step
     "8k4ref": (7680, 4320, 64, 64, 4, 2, 32, 32),     # configs[4]
+    "tq1080p": (1920, 1080, 64, 0, 1, 16, 32, 32),    # configs[2]: transform/quant only (see --tu), no search
 }
 
 
@@ -104,6 +105,75 @@ def cpu_baseline(frames_np, ctu, rng, nrefs, tu, qp, gpu_mv, gpu_level, gpu_rec,
     }
 
 
+def tq_only(args, world, rank, backend, nw, nh, ctu, fps, tu, qp):
+    """BASELINE configs[2]: the intra-style transform/quant path alone -- residual against the co-located
+    block of the previous frame, forward transform + quant + dequant + inverse + reconstruction
+    (x265amd_tq_roundtrip), SLICE_I rounding, no search."""
+    import torch.distributed as dist
+    frames_np = make_frames(nw, nh, ctu, 16, fps + 1, seed=12345 + 1000 * rank)
+    h, w = frames_np.shape[1:]
+    frames = torch.from_numpy(frames_np).cuda()
+    cur, pred = frames[1:], frames[:-1]
+    level = torch.empty((fps, h, w), dtype=torch.int16, device="cuda")
+    sums = torch.empty((fps, (h // tu) * (w // tu)), dtype=torch.int32, device="cuda")
+    rec = torch.empty((fps, h, w), dtype=torch.uint8, device="cuda")
+
+    def step():
+        x265_amd.tq_roundtrip(cur, pred, tu, qp, x265_amd.SLICE_I, out=(level, sums, rec))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        ms = e0.elapsed_time(e1) / args.steps
+        tq_bytes = 5 * w * h * fps
+        out = {
+            "metric": "TQ Mpixels/s", "value": round(nw * nh * fps * world * args.steps / elapsed / 1e6, 2),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "i32", "data": "synthetic",
+            "config": {"workload": f"{nw}x{nh} 8-bit luma (padded {w}x{h}), {tu}x{tu} residual + DCT + quant + dequant + "
+                                   f"IDCT + recon, QP{qp}, I-slice rounding, prediction = co-located block of the previous "
+                                   f"frame; {fps} frames per step per GPU", "name": args.workload, "tu": tu},
+            "roofline": {"kernel": f"tq_kernel<{tu}, 3>", "bound": "hbm", "achieved": round(tq_bytes / (ms * 1e-3) / 1e9, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tq_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "traffic": None, "algorithmic_bytes_per_launch": tq_bytes, "avg_launch_ms": round(ms, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle
+            orc = pyoracle.Oracle()
+            threads = min(16, os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            lvl, _ = orc.tq_forward(frames_np[1], frames_np[0], tu, qp, 0, nthreads=threads)
+            orec = orc.tq_inverse(lvl, frames_np[0], tu, qp, 0, nthreads=threads)
+            dt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(nw * nh / dt / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                                   "sample": f"one whole frame, forward + inverse, in {dt:.3f} s (oracle port, OpenMP)",
+                                   "parity_with_gpu_on_sample": bool((lvl == level[0].cpu().numpy()).all()
+                                                                     and (orec == rec[0].cpu().numpy()).all())}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +182,7 @@ def main():
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--me-method", default="sea", choices=["sea", "brute"],
                     help="sea: exact successive elimination (default); brute: every candidate's SAD. Same output.")
+    ap.add_argument("--tu", type=int, default=None, choices=[4, 8, 16, 32], help="transform size (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -124,13 +195,23 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local)
-    x265_amd.init(local)
+    # one process per GPU.  X265AMD_DIST_BACKEND=gloo is for rehearsing the multi-rank path on a box with
+    # fewer GPUs than ranks (ranks then share devices); the driver's runs use nccl (= RCCL).
+    backend = os.environ.get("X265AMD_DIST_BACKEND", "nccl")
+    dev_index = local if backend == "nccl" else local % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    x265_amd.init(dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
 
     nw, nh, ctu, rng, nrefs, fps, tu, qp = WORKLOADS[args.workload]
+    tu = args.tu or tu
+    if args.workload == "tq1080p":
+        return tq_only(args, world, rank, backend, nw, nh, ctu, fps, tu, qp)
     frames_np = make_frames(nw, nh, ctu, rng, fps + nrefs, seed=12345 + 1000 * rank)
     h, w = frames_np.shape[1:]
     frames = torch.from_numpy(frames_np).cuda()
@@ -157,7 +238,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     me_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
