@@ -7,9 +7,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import x265_amd
 from x265_amd import synth, api
 x265_amd.init(0)
-W, H, R = 1920, 1088, 64
+W, H, R = (int(os.environ.get(k, d)) for k, d in (('SEA_W', 1920), ('SEA_H', 1088), ('SEA_R', 64)))
 NF = int(sys.argv[1]) if len(sys.argv) > 1 else 2
-seq = np.stack([synth.pad_plane(f, 64) for f in synth.make_sequence(1920, 1080, NF + 1, search_range=R, seed=12345)])
+seq = np.stack([synth.pad_plane(f, 64) for f in synth.make_sequence(W, H, NF + 1, search_range=R, seed=12345)])
 fr = torch.from_numpy(seq).cuda()
 nctu = (W // 64) * (H // 64)
 stats = torch.zeros((NF, nctu, 16), dtype=torch.int32, device="cuda")
@@ -27,7 +27,7 @@ for i, n in enumerate(names):
     print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
 for i, n in bnames.items():
     print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
-interior = [i for i in range(nctu_all) if 2 <= (i % nctu) % 30 <= 27 and 2 <= (i % nctu) // 30 <= 14]
+interior = [i for i in range(nctu_all) if 2 <= (i % nctu) % (W // 64) <= W // 64 - 3 and 2 <= (i % nctu) // (W // 64) <= H // 64 - 3]
 print("interior CTUs:", {n: float(s[interior, i].mean()) for i, n in enumerate(names)})
 print("CTUs with a second pass:", int((s[:, 1] > 0).sum()), "of", nctu_all,
       "| rounds per CTU (mean):", float((np.ceil(s[:, 0] / 128) + np.ceil(s[:, 1] / 128)).mean()))
@@ -66,7 +66,7 @@ heavy = n1 > 512
 print("heavy CTUs: start time relative to the CU's first start (cycles), quantiles 50/90/100:",
       np.percentile([t0[i] - t0[cu == cu[i]].min() for i in np.nonzero(heavy)[0]], [50, 90, 100]).tolist())
 miss = np.nonzero((n1 > 512) & (est < 1024))[0]
-print("missed heavy CTUs (n1, est):", [(int(n1[i]), int(est[i])) for i in miss])
+print("missed heavy CTUs:", len(miss), "first (n1, est):", [(int(n1[i]), int(est[i])) for i in miss[:8]])
 for lo, hi in ((0, 450), (450, 500), (500, 600), (600, 768), (768, 1024), (1024, 2048), (2048, 1 << 30)):
     m = (est >= lo) & (est < hi)
     if m.any():

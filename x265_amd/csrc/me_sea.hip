@@ -123,7 +123,6 @@ __device__ __forceinline__ int lb_bin(uint32_t lb)
 }
 
 constexpr int kMaxChain = 20;     // chain steps of 16 rows: ndy <= 257 (R <= 128) needs 17
-constexpr int kSeaThreads = 512;  // 8 waves (exact kernel)
 constexpr int kBoundsThreads = 512;  // 8 waves, 4 workgroups per CU
 constexpr uint32_t kIllegal = 1u << 30;  // > any bound (16 * 65280)
 constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or already scheduled
@@ -138,6 +137,7 @@ struct SeaHdr {  // per (plane, CTU)
     uint32_t pad;
 };
 constexpr int kFirst = 256;   // first batch: two rounds of 128 groups
+constexpr int kMaxWgLists = 512;  // persistent workgroups that may need a schedule slice in the workspace
 constexpr int kClasses = 4;   // launch-order classes (kClasses + 1 <= 8 counters: box16_h zeroes 8) of the work estimate, heaviest first
 __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est >= 1024 ? 1 : est >= 600 ? 2 : 3; }
 
@@ -451,11 +451,12 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
 // comes from list0 with its entries already in registers when the window has landed; a second pass is
 // needed only if a group outside it has a bound <= the best SAD found (hdr.rest_min tells without a scan).
 // ---------------------------------------------------------------------------------------------
-template <bool kStats>
-__global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t *__restrict__ cur_base,
+template <bool kStats, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t *__restrict__ cur_base,
                                                                    const uint8_t *__restrict__ ref_base,
                                                                    const uint16_t *__restrict__ gl,
                                                                    const uint16_t *__restrict__ list0,
+                                                                   uint16_t *__restrict__ wg_list,
                                                                    const SeaHdr *__restrict__ hdr,
                                                                    const uint32_t *__restrict__ order,
                                                                    uint32_t *__restrict__ ctrl, int total,
@@ -465,8 +466,12 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *win = smem;                                                     // [win_rows][pitch] reference window
-    uint16_t *list = reinterpret_cast<uint16_t *>(smem + win_dwords);         // second-pass schedule
-    __shared__ __attribute__((aligned(16))) uint32_t part[2][8 * 64 * 4];     // partial SADs: [round & 1][wave][lane][4 dx]
+    constexpr int kThreads = WAVES * 64, kRound = 16 * WAVES;  // WAVES / 4 sets of 64 groups per round
+    // second-pass schedule: in LDS behind the window (8 waves), or in this workgroup's own slice of the
+    // workspace when the LDS is needed for a +-128 window and 16 waves' partial sums (same-CU L1: coherent
+    // across the barrier for the waves of one workgroup)
+    uint16_t *list = WAVES == 8 ? reinterpret_cast<uint16_t *>(smem + win_dwords) : wg_list + (size_t)blockIdx.x * gl_pitch;
+    __shared__ __attribute__((aligned(16))) uint32_t part[2][WAVES * 64 * 4];  // partial SADs: [round & 1][wave][lane][4 dx]
     __shared__ unsigned long long best_key;
     __shared__ int list_n, next_ctu;
 
@@ -529,8 +534,9 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     // the first batch's entries of this lane (rounds 0 and 1) and the header: in flight with the window
     const long long t_begin = kStats ? clock64() : 0;
     const int e_hi = gl_pitch - 1;
-    int ent0 = (int)l0[min(set * 64 + lane, e_hi)];
-    int ent1 = (int)l0[min(128 + set * 64 + lane, e_hi)];
+    int ent0[kFirst / kRound];
+#pragma unroll
+    for (int r = 0; r < kFirst / kRound; r++) ent0[r] = (int)l0[min(r * kRound + set * 64 + lane, e_hi)];
     const SeaHdr h = hdr[ctu_id];
 
     // ---- stage the reference window: a wave per row, a lane per dword, 13 rows in flight ----
@@ -540,18 +546,18 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
         const int gx = L.wx0 + 4 * wq;
         const bool colok = wq < L.pitch;
         const bool inpic = colok && gx + 4 <= g.width;
-        for (int row0 = wave; row0 < L.win_rows; row0 += 8 * kWinInFlight) {
+        for (int row0 = wave; row0 < L.win_rows; row0 += WAVES * kWinInFlight) {
             uint32_t v[kWinInFlight];
 #pragma unroll
             for (int j = 0; j < kWinInFlight; j++) {
-                const int row = row0 + 8 * j, gy = cy + L.dylo + row;
+                const int row = row0 + WAVES * j, gy = cy + L.dylo + row;
                 v[j] = 0;  // outside the picture: only ever paired with candidates that are masked below
                 if (inpic && row < L.win_rows && gy < g.height)
                     v[j] = *reinterpret_cast<const uint32_t *>(ref + (int64_t)gy * g.stride + gx);
             }
 #pragma unroll
             for (int j = 0; j < kWinInFlight; j++) {
-                const int row = row0 + 8 * j;
+                const int row = row0 + WAVES * j;
                 if (colok && row < L.win_rows) win[row * L.pitch + wq] = v[j];
             }
         }
@@ -647,8 +653,9 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     };
 
     // ---- pass 0: the first batch ----
-    run_round(ent0, set * 64 + lane < n0);
-    if (n0 > 128) run_round(ent1, 128 + set * 64 + lane < n0);
+#pragma unroll
+    for (int r = 0; r < kFirst / kRound; r++)
+        if (r == 0 || n0 > r * kRound) run_round(ent0[r], r * kRound + set * 64 + lane < n0);
     __syncthreads();
 
     const long long t_pass0 = kStats ? clock64() : 0;
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
     if (rest_min != kNone && (rest_min << 4) <= best_sad) {
         // sweep 1 counts the wave's takers, ONE LDS atomic reserves their slots, sweep 2 fills them in scan order
         int wcount = 0;
-        for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
+        for (int g0 = 0; g0 < L.ngroups; g0 += kThreads) {
             const int gi = g0 + tid;
             const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
             wcount += (int)__popcll(__ballot(v != kNone && (v << 4) <= best_sad));
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
         if (lane == 0 && wcount) wbase = atomicAdd(&list_n, wcount);
         wbase = __builtin_amdgcn_readfirstlane(wbase);
         if (wcount) {
-            for (int g0 = 0; g0 < L.ngroups; g0 += kSeaThreads) {
+            for (int g0 = 0; g0 < L.ngroups; g0 += kThreads) {
                 const int gi = g0 + tid;
                 const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
                 const bool take = v != kNone && (v << 4) <= best_sad;
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(kSeaThreads, 4) void sea_exact_kernel(const uint8_t
         }
         __syncthreads();
         n1 = list_n;
-        for (int base = 0; base < n1; base += 128) {
+        for (int base = 0; base < n1; base += kRound) {
             const int li = base + set * 64 + lane;
             const bool have = li < n1;
             run_round((int)list[have ? li : 0], have);
@@ -770,7 +777,31 @@ extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, i
            + 2 * align256(sizeof(uint16_t) * per_ctu * nctu * planes)      // bounds + first-batch list per CTU
            + align256(sizeof(SeaHdr) * nctu * planes)
            + align256(sizeof(uint32_t) * kClasses * nctu * planes)         // launch-order queues of the exact kernel
-           + 256;                                                          // their counters
+           + 256                                                           // their counters
+           + align256(sizeof(uint16_t) * per_ctu * kMaxWgLists);           // second-pass schedules of 16-wave workgroups
+}
+
+// as many workgroups as the chip holds at once (LDS- and register-bound), each looping over CTUs
+template <int WAVES>
+static int launch_exact(size_t lds, hipStream_t st, const uint8_t *d_cur, const uint8_t *d_ref, const uint16_t *gl,
+                        const uint16_t *list0, uint16_t *wg_list, const SeaHdr *hdr, const uint32_t *order, uint32_t *ctrl,
+                        int total, x265amd_mv *d_out, const MeGeom &g, int gl_pitch, int win_dwords)
+{
+    const void *fn = g_me_stats ? (const void *)sea_exact_kernel<true, WAVES> : (const void *)sea_exact_kernel<false, WAVES>;
+    X265AMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0;
+    X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVES * 64, lds));
+    if (per_cu < 1) return X265AMD_ERR_LDS;
+    int resident = per_cu * cu_count();
+    if (WAVES == 16 && resident > kMaxWgLists) resident = kMaxWgLists;  // schedule slices in the workspace
+    const dim3 grid((unsigned)(total < resident ? total : resident));
+    if (g_me_stats)
+        hipLaunchKernelGGL((sea_exact_kernel<true, WAVES>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
+                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
+    else
+        hipLaunchKernelGGL((sea_exact_kernel<false, WAVES>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
+                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
+    return X265AMD_OK;
 }
 
 extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
@@ -797,9 +828,17 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     const int gl_pitch = (max_groups + 7) & ~7;
     if (max_groups > 0xffff || max_ndy > 16 * kMaxChain) return X265AMD_ERR_LDS;  // 16-bit schedule entries
     const int win_dwords = max_rows * max_pitch;
-    size_t lds_exact = (size_t)win_dwords * 4 + (((size_t)max_groups * 2 + 15) & ~(size_t)15);
-    if (const char *pad = getenv("X265AMD_SEA_LDS_PAD")) lds_exact += (size_t)atoi(pad);  // occupancy experiments only
-    if (lds_exact + 17408 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;  // + the kernel's static LDS
+    const size_t list_bytes = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
+    // 8-wave workgroups (window + schedule in LDS, 16 KB of partial sums) when two of them fit a CU;
+    // otherwise ONE 16-wave workgroup per CU (window only + 32 KB of partial sums, schedule in the workspace)
+    size_t lds8 = (size_t)win_dwords * 4 + list_bytes;
+    if (const char *pad = getenv("X265AMD_SEA_LDS_PAD")) lds8 += (size_t)atoi(pad);  // occupancy experiments only
+    const size_t lds16 = (size_t)win_dwords * 4;
+    const size_t lds_cap = (size_t)lds_limit_bytes();
+    bool waves16 = 2 * (lds8 + 17408) > lds_cap;
+    if (const char *e = getenv("X265AMD_SEA_WAVES")) waves16 = atoi(e) == 16;  // A/B experiments only
+    if (waves16 && lds16 + 33792 > lds_cap) waves16 = false;
+    if (!waves16 && lds8 + 17408 > lds_cap) return X265AMD_ERR_LDS;  // + the kernel's static LDS
     const size_t lds_bounds = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
 
     const size_t nctu = (size_t)(width / 64) * (height / 64);
@@ -843,23 +882,15 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     hipLaunchKernelGGL(sea_bounds_kernel, grid, dim3(kBoundsThreads), lds_bounds, st, d_cur, pbuf, gl, list0, hdr, order,
                        ctrl, g, gl_pitch, g_me_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
-    X265AMD_HIP(hipFuncSetAttribute((const void *)sea_exact_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds_exact));
-    // as many workgroups as the chip holds at once (LDS- and register-bound), each looping over CTUs
-    int per_cu = 0;
-    X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)sea_exact_kernel<false>, kSeaThreads, lds_exact));
-    if (per_cu < 1) return X265AMD_ERR_LDS;
-    const int resident = per_cu * cu_count();
-    const dim3 egrid((unsigned)(total < resident ? total : resident));
-    if (g_me_stats) {
-        X265AMD_HIP(hipFuncSetAttribute((const void *)sea_exact_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_exact));
-        hipLaunchKernelGGL(sea_exact_kernel<true>, egrid, dim3(kSeaThreads), lds_exact, st, d_cur, d_ref, gl, list0, hdr,
-                           order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
-    } else {
-        hipLaunchKernelGGL(sea_exact_kernel<false>, egrid, dim3(kSeaThreads), lds_exact, st, d_cur, d_ref, gl, list0, hdr,
-                           order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
-    }
+    uint16_t *wg_list = (uint16_t *)(ws + 256);
+    int status;
+    if (waves16)
+        status = launch_exact<16>(lds16, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch,
+                                  win_dwords);
+    else
+        status = launch_exact<8>(lds8, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch,
+                                 win_dwords);
+    if (status != X265AMD_OK) return status;
     if (timing) (void)hipEventRecord(g_me_ev[4], st);
     return hip_status(hipGetLastError());
 }
