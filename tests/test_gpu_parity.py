@@ -360,3 +360,54 @@ def test_closed_loop_gop_vs_oracle(gpu, oracle):
             np.testing.assert_array_equal(glevel[s], np.concatenate(lev))
             assert hashlib.md5(rec_gpu[s].tobytes()).hexdigest() == hashlib.md5(ref_cpu[s].tobytes()).hexdigest(), (s, t)
     assert enc.poc == T - 1
+
+
+def test_me_sea_strides_batches_and_workspace(gpu, oracle):
+    """The successive-elimination entry point on what the pipeline never exercises: a row stride wider
+    than the picture, a batch whose frames are not back to back, a caller workspace that is reused, and
+    the refusals (workspace too small or misaligned, CTU other than 64)."""
+    from x265_amd import synth, api
+    W, H, R, F = 192, 128, 20, 3
+    seq = synth.make_sequence(W, H, F + 1, search_range=R, seed=41)
+    big = torch.zeros((F + 1, H + 8, W + 64), dtype=torch.uint8, device="cuda")   # padded rows and frames
+    big[:, :H, :W] = dev(seq)
+    frames = big[:, :H, :W]                                                       # stride W + 64, frame stride (H + 8) * (W + 64)
+    ws = torch.empty(api.me_workspace_bytes(W, H, R, F, 1) + 64, dtype=torch.uint8, device="cuda")
+    for _ in range(2):                                                            # the second call reuses the workspace as it was left
+        mv = gpu.me_fullsearch(frames[1:], frames[:-1], 64, R, method="sea", workspace=ws)
+        got = gpu.mv_to_numpy(mv)
+        for f in range(F):
+            np.testing.assert_array_equal(got[f, 0], oracle.me_fullsearch(seq[f + 1], seq[f], 64, R, nthreads=8))
+    with pytest.raises(gpu.X265AmdError):
+        gpu.me_fullsearch(frames[1:], frames[:-1], 64, R, method="sea", workspace=ws[:1024])   # too small
+    with pytest.raises(gpu.X265AmdError):
+        gpu.me_fullsearch(frames[1:], frames[:-1], 64, R, method="sea", workspace=ws[4:])      # not 16-byte aligned
+    with pytest.raises(gpu.X265AmdError):
+        gpu.me_fullsearch(frames[1:], frames[:-1], 32, R, method="sea", workspace=ws)          # SEA is CTU 64 only
+
+
+def test_tq_mv_shift_chroma_vs_oracle(gpu, oracle):
+    """mv_shift of the TQ descriptor: chroma planes predicted with the luma vectors >> 1 (arithmetic shift,
+    negative odd vectors included) equal the oracle fed with the halved vectors."""
+    rng = np.random.default_rng(8)
+    H, W = 64, 96                                        # chroma plane of a 192x128 picture: 3 x 2 blocks of 32
+    src = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    ref = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    mv = np.zeros(6, dtype=gpu.MV_DTYPE)
+    mv["mvx"] = [-7, 5, -64, 63, 1, -1]                  # luma units; block x0 = 0 / 32 / 64 keeps them inside
+    mv["mvy"] = [3, -5, 9, -63, -1, 64]
+    # keep every displaced 32x32 block inside the plane
+    for i in range(6):
+        bx, by = (i % 3) * 32, (i // 3) * 32
+        mv["mvx"][i] = np.clip(mv["mvx"][i] >> 1, -bx, W - 32 - bx) * 2 + (mv["mvx"][i] & 1)
+        mv["mvy"][i] = np.clip(mv["mvy"][i] >> 1, -by, H - 32 - by) * 2 + (mv["mvy"][i] & 1)
+    half = mv.copy()
+    half["mvx"] >>= 1
+    half["mvy"] >>= 1
+    dmv = torch.from_numpy(mv.view(np.int32).reshape(1, 6, 2).copy()).cuda()
+    level, sums, rec = gpu.tq_roundtrip(dev(src), dev(ref), 16, 29, 1, mv=dmv, mv_ctu=32, mv_shift=1)
+    ol, os_ = oracle.tq_forward(src, ref, 16, 29, 1, mv=half, mv_ctu=32)
+    orec = oracle.tq_inverse(ol, ref, 16, 29, 1, mv=half, mv_ctu=32)
+    np.testing.assert_array_equal(host(level)[0], ol)
+    np.testing.assert_array_equal(host(sums)[0].astype(np.uint32), os_)
+    np.testing.assert_array_equal(host(rec)[0], orec)

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void box16_h(const uint8_t *__restrict__ ref_b
 // the two sub-blocks of one candidate that sit side by side share a dword, so that one v_sad_u16
 // adds both |differences| to the candidate's bound.  A thread owns columns 2xp, 2xp+1 and their
 // partners 16 to the right (packed u16 pairs) and a run of rows.
-constexpr int kBoxVRows = 32;
+constexpr int kBoxVRows = 64;
 __global__ __launch_bounds__(256) void box16_v(const uint16_t *__restrict__ hbuf, uint32_t *__restrict__ pbuf, int width,
                                                int height)
 {
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void box16_v(const uint16_t *__restrict__ hbuf
         af += hf[(int64_t)(y0 + k) * wp];
     }
     p[(int64_t)y0 * wp] = make_uint2((an & 0xffffu) | (af << 16), (an >> 16) | (af & 0xffff0000u));
+#pragma unroll 8
     for (int y = y0 + 1; y < y0 + kBoxVRows && y + 16 <= height; y++) {
         // packed u16 pair: take the old row out first (each half contains it: no borrow), then the
         // new row in (each half <= 16 * 4080 < 2^16: no carry)
@@ -787,10 +788,23 @@ static int launch_exact(size_t lds, hipStream_t st, const uint8_t *d_cur, const 
                         const uint16_t *list0, uint16_t *wg_list, const SeaHdr *hdr, const uint32_t *order, uint32_t *ctrl,
                         int total, x265amd_mv *d_out, const MeGeom &g, int gl_pitch, int win_dwords)
 {
-    const void *fn = g_me_stats ? (const void *)sea_exact_kernel<true, WAVES> : (const void *)sea_exact_kernel<false, WAVES>;
-    X265AMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 0;
-    X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, WAVES * 64, lds));
+    const bool st_variant = g_me_stats != nullptr;
+    const void *fn = st_variant ? (const void *)sea_exact_kernel<true, WAVES> : (const void *)sea_exact_kernel<false, WAVES>;
+    // the LDS opt-in and the occupancy query are host round trips: once per (variant, LDS size)
+    // and device (a cache of one entry: a process drives one GPU)
+    static size_t seen_lds[2] = {~(size_t)0, ~(size_t)0};
+    static int seen_per_cu[2] = {0, 0}, seen_dev[2] = {-1, -1};
+    int dev = -1;
+    X265AMD_HIP(hipGetDevice(&dev));
+    if (seen_lds[st_variant] != lds || seen_dev[st_variant] != dev) {
+        X265AMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int q = 0;
+        X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, WAVES * 64, lds));
+        seen_per_cu[st_variant] = q;
+        seen_lds[st_variant] = lds;
+        seen_dev[st_variant] = dev;
+    }
+    const int per_cu = seen_per_cu[st_variant];
     if (per_cu < 1) return X265AMD_ERR_LDS;
     int resident = per_cu * cu_count();
     if (WAVES == 16 && resident > kMaxWgLists) resident = kMaxWgLists;  // schedule slices in the workspace
