@@ -232,21 +232,21 @@ def test_me_multi_reference(gpu, oracle, method):
             np.testing.assert_array_equal(got[i, r], want, f"frame {i} ref {r}")
 
 
-@pytest.mark.parametrize("method", ["brute", "sea"])
-def test_me_1080p_properties(gpu, oracle, method):
-    """BASELINE.json configs[1] at full size (1920x1088, CTU 64, R 64).  The CPU oracle needs
-    ~0.1 s per CTU, so: (a) exact comparison on every 17th CTU, (b) for ALL CTUs the
-    returned cost is the true SAD at the returned vector (recomputed by the independent
-    batched-SAD kernel) and is no worse than the zero vector and 8 random legal candidates."""
+def _me_fullsize_properties(gpu, oracle, method, W, H, R, first, step):
+    """(a) exact comparison with the CPU oracle on CTUs first, first+step, ..; (b) for ALL CTUs the
+    returned cost is the true SAD at the returned vector (recomputed by the independent batched-SAD
+    kernel), the vector is legal, and no worse than the zero vector and 8 random legal candidates;
+    (c) the two entry points agree on every CTU."""
     from x265_amd import synth
-    W, H, R = 1920, 1088, 64
     seq = synth.make_sequence(W, H, 2, search_range=R, seed=12345)
     cur, ref = dev(seq[1]), dev(seq[0])
     mv = gpu.mv_to_numpy(gpu.me_fullsearch(cur, ref, 64, R, method=method))[0, 0]
+    other = gpu.mv_to_numpy(gpu.me_fullsearch(cur, ref, 64, R, method="brute" if method == "sea" else "sea"))[0, 0]
+    np.testing.assert_array_equal(mv, other)
     ncx = W // 64
     nctu = mv.size
-    want = oracle.me_fullsearch(seq[1], seq[0], 64, R, first=3, step=17, count=-1, nthreads=16)
-    idx = np.arange(3, nctu, 17)
+    want = oracle.me_fullsearch(seq[1], seq[0], 64, R, first=first, step=step, count=-1, nthreads=16)
+    idx = np.arange(first, nctu, step)
     np.testing.assert_array_equal(mv[idx], want[idx])
     cx = (np.arange(nctu) % ncx) * 64
     cy = (np.arange(nctu) // ncx) * 64
@@ -265,6 +265,19 @@ def test_me_1080p_properties(gpu, oracle, method):
         ro = dev(((cy + dy) * W + cx + dx).astype(np.int32))
         s = host(gpu.sad_blocks(64, 64, cur.view(-1), W, ref.view(-1), W, so, ro)).astype(np.uint32)
         assert (mv["sad"] <= s).all()
+
+
+@pytest.mark.parametrize("method", ["brute", "sea"])
+def test_me_1080p_properties(gpu, oracle, method):
+    """BASELINE.json configs[1] at full size (1920x1088, CTU 64, R 64); the CPU oracle needs ~0.1 s per
+    CTU, hence every 17th CTU."""
+    _me_fullsize_properties(gpu, oracle, method, 1920, 1088, 64, 3, 17)
+
+
+def test_me_4k_properties(gpu, oracle):
+    """BASELINE.json configs[3] at full size (3840x2176, R 128): the +-128 window leaves room for one
+    workgroup per CU only, which is the 16-wave shape of the exact kernel.  Oracle on every 97th CTU."""
+    _me_fullsize_properties(gpu, oracle, "sea", 3840, 2176, 128, 5, 97)
 
 
 def test_me_sea_equals_exhaustive_on_hostile_content(gpu):
