@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
                                                                  uint16_t *__restrict__ gl, uint16_t *__restrict__ list0,
                                                                  SeaHdr *__restrict__ hdr, uint32_t *__restrict__ order,
                                                                  uint32_t *__restrict__ ctrl, const MeGeom g, int gl_pitch,
-                                                                 uint32_t *__restrict__ stats)
+                                                                 int nplanes, uint32_t *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint16_t *glb = reinterpret_cast<uint16_t *>(smem);  // [ndy][ngx]
@@ -164,13 +164,23 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     __shared__ uint16_t sel_ent[kFirst];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int ctx = blockIdx.x, cty = blockIdx.y;
-    const int f = blockIdx.z / g.nrefs;
+    // XCD-aware order: workgroup w runs on XCD w % 8 (round-robin dispatch), each XCD has its own L2,
+    // and neighbouring CTUs share two thirds of their box-sum windows.  So XCD k takes the k-th
+    // contiguous eighth of the CTUs, in raster order (PMC: 905 -> 166 MB fetched per 16 1080p frames,
+    // 0.170 -> 0.143 ms).
+    const int total = g.ctus_x * g.ctus_y * nplanes;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int base = total >> 3, rem = total & 7;
+    if (slot >= base + (xcd < rem ? 1 : 0)) return;  // grid is rounded up to a multiple of 8 (block-uniform exit)
+    const int ctu_lin = xcd * base + (xcd < rem ? xcd : rem) + slot;
+    const int plane = ctu_lin / (g.ctus_x * g.ctus_y), cin = ctu_lin - plane * (g.ctus_x * g.ctus_y);
+    const int cty = cin / g.ctus_x, ctx = cin - cty * g.ctus_x;
+    const int f = plane / g.nrefs;
     const int cx = ctx * 64, cy = cty * 64;
     const SeaLayout L = sea_layout(g.width, g.height, g.range, cx, cy);
     const uint8_t *cur = cur_base + f * g.cur_fs;
-    const uint32_t *P = pbuf + (int64_t)blockIdx.z * g.height * g.width;
-    const int64_t ctu_id = ((int64_t)blockIdx.z * g.ctus_y + cty) * g.ctus_x + ctx;
+    const uint32_t *P = pbuf + (int64_t)plane * g.height * g.width;
+    const int64_t ctu_id = ctu_lin;
 
     const long long tb0 = stats ? clock64() : 0;
     if (tid < kBins) hist[tid] = 0;
@@ -433,7 +443,6 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         h.pad = 0;
         hdr[ctu_id] = h;
         // launch order of kernel 2: longest first, in kClasses classes of the estimate (a queue each)
-        const uint32_t total = gridDim.x * gridDim.y * gridDim.z;
         if (stats) {
             stats[16 * ctu_id + 10] = (uint32_t)(tb1 - tb0);        // cycles: sub-block sums of the CTU
             stats[16 * ctu_id + 11] = (uint32_t)(tb2 - tb1);        //         bounds
@@ -441,7 +450,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             stats[16 * ctu_id + 13] = (uint32_t)(clock64() - tb3);  //         write-out
         }
         const int cls = sea_class(est_n);
-        order[(size_t)cls * total + atomicAdd(&ctrl[cls], 1u)] = (uint32_t)ctu_id;
+        order[(size_t)cls * (uint32_t)total + atomicAdd(&ctrl[cls], 1u)] = (uint32_t)ctu_id;
     }
 }
 
@@ -892,9 +901,8 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     g.cur_fs = cur_frame_stride;
     g.ref_fs = ref_frame_stride;
     g.ref_rs = ref_ref_stride;
-    const dim3 grid(g.ctus_x, g.ctus_y, (unsigned)nplanes);
-    hipLaunchKernelGGL(sea_bounds_kernel, grid, dim3(kBoundsThreads), lds_bounds, st, d_cur, pbuf, gl, list0, hdr, order,
-                       ctrl, g, gl_pitch, g_me_stats);
+    hipLaunchKernelGGL(sea_bounds_kernel, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
+                       pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, g_me_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;
