@@ -10,7 +10,7 @@
 constexpr int BLOCKS = 256;  // 16-row blocks per wave
 constexpr int PITCH = 65;
 
-template <int LDS, int SLOAD, int WAVES>
+template <int LDS, int SLOAD, int WAVES, int PACKED = 0>
 __global__ __launch_bounds__(WAVES * 64) void k(uint32_t *__restrict__ out, const uint32_t *__restrict__ cur, int cstr,
                                                 uint32_t seed, int pitch)
 {
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(WAVES * 64) void k(uint32_t *__restrict__ out, cons
             const uint32_t *p_ = wrow + (r) * pitch;                                          \
             _Pragma("unroll") for (int k2 = 0; k2 < 17; k2++) d[k2] = p_[k2];                 \
         }                                                                                     \
-        if (SLOAD) { _Pragma("unroll") for (int k2 = 0; k2 < 16; k2++) S[k2] = crow[(r) * cstr + k2]; } \
+        if (SLOAD) { _Pragma("unroll") for (int k2 = 0; k2 < 16; k2++) S[k2] = crow[(r) * (PACKED ? 16 : cstr) + k2]; } \
     }
 #define SEA_ROW(d, S)                                                                                   \
     _Pragma("unroll") for (int k2 = 0; k2 < 16; k2++)                                                  \
@@ -69,11 +69,11 @@ __global__ __launch_bounds__(WAVES * 64) void k(uint32_t *__restrict__ out, cons
     if (blockIdx.x == 7 && lane == 0) ((uint64_t *)out)[512 + wave] = c1 - c0;
 }
 
-template <int LDS, int SLOAD, int WAVES> static void run(const char *name, uint32_t *d_out, uint32_t *d_cur, int pitch)
+template <int LDS, int SLOAD, int WAVES, int PACKED = 0> static void run(const char *name, uint32_t *d_out, uint32_t *d_cur, int pitch)
 {
     uint64_t h[16];
     for (int rep = 0; rep < 2; rep++)
-        hipLaunchKernelGGL((k<LDS, SLOAD, WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, d_out, d_cur, 480, 1u + rep, pitch);
+        hipLaunchKernelGGL((k<LDS, SLOAD, WAVES, PACKED>), dim3(256), dim3(WAVES * 64), 0, 0, d_out, d_cur, 480, 1u + rep, pitch);
     hipDeviceSynchronize();
     hipMemcpy(h, (uint64_t *)d_out + 512, sizeof(h), hipMemcpyDeviceToHost);
     uint64_t mx = 0;
@@ -94,6 +94,8 @@ int main()
     run<0, 1, 16>("qsad + s_load", d_out, d_cur, PITCH);
     run<1, 1, 16>("qsad + LDS row + s_load (the kernel)", d_out, d_cur, PITCH);
     run<1, 1, 8>("qsad + LDS row + s_load", d_out, d_cur, PITCH);
+    run<1, 1, 8, 1>("same, current block packed (immediate offsets)", d_out, d_cur, PITCH);
+    run<1, 1, 16, 1>("same, current block packed (immediate offsets)", d_out, d_cur, PITCH);
     run<1, 1, 4>("qsad + LDS row + s_load", d_out, d_cur, PITCH);
     return 0;
 }

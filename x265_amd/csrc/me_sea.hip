@@ -134,13 +134,13 @@ __device__ __forceinline__ uint32_t lb_store(uint32_t lb) { return lb >> 4; }
 struct SeaHdr {  // per (plane, CTU)
     uint32_t n0;        // groups in the first batch (<= kFirst)
     uint32_t rest_min;  // smallest stored bound among the groups NOT in it (kNone: none left)
-    uint32_t est;       // groups with a bound within 2x of the first batch's threshold (work estimate)
+    uint32_t est;       // work estimate: groups with a bound <= the probed SAD (an upper bound of n0 + second pass)
     uint32_t pad;
 };
 constexpr int kFirst = 256;   // first batch: two rounds of 128 groups
 constexpr int kMaxWgLists = 512;  // persistent workgroups that may need a schedule slice in the workspace
 constexpr int kClasses = 4;   // launch-order classes (kClasses + 1 <= 8 counters: box16_h zeroes 8) of the work estimate, heaviest first
-__device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est >= 1024 ? 1 : est >= 600 ? 2 : 3; }
+__device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est >= 1024 ? 1 : est >= 850 ? 2 : 3; }
 
 // ---------------------------------------------------------------------------------------------
 // Kernel 1: bounds.  No window, 9 KB of LDS => high occupancy hides the box-sum loads.
@@ -148,6 +148,7 @@ __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est
 //        list0[plane][ctu][..] the first batch (the kFirst groups of the lowest histogram bins), hdr
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
+                                                                   const uint8_t *__restrict__ ref_base,
                                                                  const uint32_t *__restrict__ pbuf,
                                                                  uint16_t *__restrict__ gl, uint16_t *__restrict__ list0,
                                                                  SeaHdr *__restrict__ hdr, uint32_t *__restrict__ order,
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     __shared__ uint32_t hist[kBins];
     __shared__ uint32_t csum[16];
     __shared__ int list_n, eq_n, pick_bin, below_n, est_n;
+    __shared__ uint32_t min_key, probe_sad, pref[kBins];
     __shared__ uint32_t rest_lb;
     __shared__ uint32_t bank_cnt[32];
     __shared__ uint16_t sel_ent[kFirst];
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     if (tid == 0) {
         list_n = 0;
         eq_n = 0;
+        min_key = 0xffffffffu;
         rest_lb = kNone;
     }
     // ---- the CTU's sub-block sums: 16 lanes per sub-block, one 16-pixel row each ----
@@ -214,6 +217,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     //      bands in registers: 4 eight-byte loads per group instead of 16 (coalesced along gx). ----
     const int a = cx + L.dxlo - L.wx0;  // window column of dxlo
     const int ndx = L.dxhi - L.dxlo + 1;
+    uint32_t my_min = 0xffffffffu;  // (stored bound << 16 | group) of the lane's best group
     {
         const int nchain = 16 * L.ngx;  // (c, gx)
         // whole sweeps of chains; a short remainder (the 33rd column of groups of a +-64 window: 16 of
@@ -263,7 +267,10 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
                     const uint32_t mn = min(min(lb[0], lb[1]), min(lb[2], lb[3]));
                     const uint32_t st = mn >= kIllegal ? kNone : lb_store(mn);
                     glb[dyi * L.ngx + gx] = (uint16_t)st;
-                    if (st != kNone) atomicAdd(&hist[lb_bin(st)], 1u);
+                    if (st != kNone) {
+                        atomicAdd(&hist[lb_bin(st)], 1u);
+                        my_min = min(my_min, (st << 16) | (uint32_t)(dyi * L.ngx + gx));
+                    }
                 }
         }
         // remainder chains, one group per lane: item i = (step m, chain r)
@@ -301,9 +308,15 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             }
             const uint32_t st = mn == 0xffffffffu ? kNone : lb_store(mn);
             glb[dyi * L.ngx + gx] = (uint16_t)st;
-            if (st != kNone) atomicAdd(&hist[lb_bin(st)], 1u);
+            if (st != kNone) {
+                atomicAdd(&hist[lb_bin(st)], 1u);
+                my_min = min(my_min, (st << 16) | (uint32_t)(dyi * L.ngx + gx));
+            }
         }
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, o));
+    if (lane == 0 && my_min != 0xffffffffu) atomicMin(&min_key, my_min);
     __syncthreads();
 
     const long long tb2 = stats ? clock64() : 0;
@@ -330,18 +343,56 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         const int pbv = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : kBins);
         const uint32_t incl = pbv < 64 ? __shfl(s0, pbv & 63) : __shfl(s1, pbv & 63);  // count through pick_bin
         const uint32_t own = pbv < 64 ? __shfl(c0, pbv & 63) : __shfl(c1, pbv & 63);
-        // work estimate for the launch order of kernel 2: groups whose bound is within 2x (four
-        // quarter-octave bins) of the first batch's threshold -- nearly all of them on content the
-        // bound cannot separate, a few hundred otherwise
-        const int eb = pbv + 4 < kBins - 1 ? pbv + 4 : kBins - 1;
-        const uint32_t est = eb < 64 ? __shfl(s0, eb & 63) : __shfl(s1, eb & 63);
+        pref[tid] = s0;
+        if (tid + 64 < kBins) pref[tid + 64] = s1;
         if (tid == 0) {
             pick_bin = pbv;
             below_n = pbv < kBins ? (int)(incl - own) : 0;
-            est_n = (int)est;
         }
+    } else if (tid < 128) {
+        // ---- probe (wave 1, beside the scan): the exact SADs of the group with the smallest bound.  Their
+        //      minimum UB is an upper bound of the final best SAD, so the groups with a bound <= UB are an
+        //      upper bound of everything kernel 2 will have to evaluate: its work estimate.  (Keeping the
+        //      probe's 33 dwords in flight across the write-out instead cost more in registers than the
+        //      latency it hid: 0.163 -> 0.191 ms.) ----
+        const uint32_t key = min_key;
+        uint32_t ub = 0xffffffffu;
+        if (key != 0xffffffffu) {  // block-uniform
+            const int gi = (int)(key & 0xffffu);
+            const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+            const int rr = plane - f * g.nrefs;
+            const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
+            const int x0 = L.wx0 + 4 * gx;
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(ref + (int64_t)(cy + L.dylo + dyi + lane) * g.stride + x0);
+            const uint32_t *cp = reinterpret_cast<const uint32_t *>(cur + (int64_t)(cy + lane) * g.stride + cx);
+            uint32_t d[17], cw[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                d[k] = rp[k];
+                cw[k] = cp[k];
+            }
+            d[16] = x0 + 68 <= g.width ? rp[16] : 0u;  // past the row end only members outside the picture read it
+            uint64_t acc16 = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                acc16 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], cw[k], acc16);  // <= 16 * 1020 per lane
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t sq = (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) sq += (uint32_t)__shfl_xor((int)sq, o);
+                const int dxi = 4 * gx + q - a;
+                if (dxi >= 0 && dxi < ndx) ub = min(ub, sq);
+            }
+        }
+        if (tid == 64) probe_sad = ub;
     }
     __syncthreads();
+    if (tid == 0) {
+        const uint32_t ub = probe_sad;
+        const uint32_t ubs = ub == 0xffffffffu ? 0u : min(ub >> 4, 0xfffeu);  // same units as the stored bounds
+        est_n = (int)pref[min(lb_bin(ubs), kBins - 1)];
+    }
     const int pb = pick_bin;
     const int nbelow = below_n;            // list0[0 .. nbelow) = bins < pb
     const int quota = kFirst - nbelow;     // list0[nbelow .. nbelow + min(quota, |bin pb|)) = bin pb
@@ -902,7 +953,7 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     g.ref_fs = ref_frame_stride;
     g.ref_rs = ref_ref_stride;
     hipLaunchKernelGGL(sea_bounds_kernel, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
-                       pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, g_me_stats);
+                       d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, g_me_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;
