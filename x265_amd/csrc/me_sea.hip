@@ -349,12 +349,27 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             pick_bin = pbv;
             below_n = pbv < kBins ? (int)(incl - own) : 0;
         }
-    } else if (tid < 128) {
-        // ---- probe (wave 1, beside the scan): the exact SADs of the group with the smallest bound.  Their
-        //      minimum UB is an upper bound of the final best SAD, so the groups with a bound <= UB are an
-        //      upper bound of everything kernel 2 will have to evaluate: its work estimate.  (Keeping the
-        //      probe's 33 dwords in flight across the write-out instead cost more in registers than the
-        //      latency it hid: 0.163 -> 0.191 ms.) ----
+    }
+    __syncthreads();
+    const int pb = pick_bin;
+    const int nbelow = below_n;            // list0[0 .. nbelow) = bins < pb
+    const int quota = kFirst - nbelow;     // list0[nbelow .. nbelow + min(quota, |bin pb|)) = bin pb
+
+    const long long tb3 = stats ? clock64() : 0;
+    // ---- write the bounds out; groups of the first batch go to list0 (scan order within a wave) and
+    //      are marked; the smallest bound left over goes to the header ----
+    // A thread takes 8 consecutive groups (one 16-byte LDS read, one 16-byte store); a wave reserves its
+    // list slots with ONE LDS atomic per counter per sweep.
+    uint16_t *glo = gl + ctu_id * gl_pitch;
+    uint16_t *lo = list0 + ctu_id * gl_pitch;
+    uint32_t rest_min = kNone;
+    const int nvec = (L.ngroups + 7) >> 3;
+    const int wtid = tid < 64 ? tid : tid - 64;  // wave 1 sits the write-out out: it runs the probe meanwhile
+    if (tid >= 64 && tid < 128) {
+        // ---- probe (wave 1, while the other seven waves write out): the exact SADs of the group with
+        //      the smallest bound.  Their minimum UB is an upper bound of the final best SAD, so the
+        //      groups with a bound <= UB are an upper bound of everything kernel 2 will have to
+        //      evaluate: its work estimate. ----
         const uint32_t key = min_key;
         uint32_t ub = 0xffffffffu;
         if (key != 0xffffffffu) {  // block-uniform
@@ -386,29 +401,10 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             }
         }
         if (tid == 64) probe_sad = ub;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t ub = probe_sad;
-        const uint32_t ubs = ub == 0xffffffffu ? 0u : min(ub >> 4, 0xfffeu);  // same units as the stored bounds
-        est_n = (int)pref[min(lb_bin(ubs), kBins - 1)];
-    }
-    const int pb = pick_bin;
-    const int nbelow = below_n;            // list0[0 .. nbelow) = bins < pb
-    const int quota = kFirst - nbelow;     // list0[nbelow .. nbelow + min(quota, |bin pb|)) = bin pb
-
-    const long long tb3 = stats ? clock64() : 0;
-    // ---- write the bounds out; groups of the first batch go to list0 (scan order within a wave) and
-    //      are marked; the smallest bound left over goes to the header ----
-    // A thread takes 8 consecutive groups (one 16-byte LDS read, one 16-byte store); a wave reserves its
-    // list slots with ONE LDS atomic per counter per sweep.
-    uint16_t *glo = gl + ctu_id * gl_pitch;
-    uint16_t *lo = list0 + ctu_id * gl_pitch;
-    uint32_t rest_min = kNone;
-    const int nvec = (L.ngroups + 7) >> 3;
-    for (int v0 = 0; v0 < nvec; v0 += kBoundsThreads) {
-        if (v0 + (tid & ~63) >= nvec) break;  // nothing left for this wave (wave-uniform; no barrier inside)
-        const int vi = v0 + tid;
+    } else
+    for (int v0 = 0; v0 < nvec; v0 += kBoundsThreads - 64) {
+        if (v0 + (wtid & ~63) >= nvec) break;  // nothing left for this wave (wave-uniform; no barrier inside)
+        const int vi = v0 + wtid;
         uint4 wv = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
         if (vi < nvec) wv = reinterpret_cast<const uint4 *>(glb)[vi];
         uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
@@ -487,6 +483,9 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         lo[pos] = (uint16_t)my_ent;
     }
     if (tid == 0) {
+        const uint32_t ub = probe_sad;  // published by the barriers since
+        const uint32_t ubs = ub == 0xffffffffu ? 0u : min(ub >> 4, 0xfffeu);  // same units as the stored bounds
+        est_n = (int)pref[min(lb_bin(ubs), kBins - 1)];
         SeaHdr h;
         h.n0 = (uint32_t)n0;
         h.rest_min = rest_lb;  // kNone: nothing left over
