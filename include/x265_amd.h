@@ -111,9 +111,10 @@ int x265amd_sad_blocks(int w, int n, const uint8_t *d_src, int stride_src, const
  *   cur(f)    = d_cur + f * cur_frame_stride
  *   ref(f, r) = d_ref + f * ref_frame_stride + r * ref_ref_stride   (strides in bytes, may be negative)
  *   d_out[(f * nrefs + r) * nctu + cty * (width / ctu) + ctx]
- * ctu in {16, 32, 64}; width, height multiples of ctu; stride a multiple of 4
- * and planes 4-byte aligned; (ctu + 2*range + 8)^2 + ctu^2 bytes must fit in LDS
- * (range <= 128 at ctu 64). */
+ * ctu in {16, 32, 64} -- the CTU or, for partition searches, the 32x32 / 16x16
+ * PU size: the same kernel serves all three; width, height multiples of ctu;
+ * stride a multiple of 4 and planes 4-byte aligned; the (ctu + 2*range + 8)^2-byte
+ * window must fit in LDS (range <= 128 at ctu 64), else X265AMD_ERR_LDS. */
 int x265amd_me_fullsearch(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
                           int stride, int ctu, int range, int nframes, int64_t cur_frame_stride,
                           int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride,

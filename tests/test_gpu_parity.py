@@ -424,3 +424,15 @@ def test_tq_mv_shift_chroma_vs_oracle(gpu, oracle):
     np.testing.assert_array_equal(host(level)[0], ol)
     np.testing.assert_array_equal(host(sums)[0].astype(np.uint32), os_)
     np.testing.assert_array_equal(host(rec)[0], orec)
+
+
+@pytest.mark.parametrize("ctu,rng_,w,h", [(64, 40, 320, 192), (32, 33, 224, 160), (16, 21, 144, 112)])
+def test_me_production_kernel_equals_basic_formulation(gpu, ctu, rng_, w, h):
+    """The qsad kernel (all three block sizes) against the independent one-candidate-per-lane
+    formulation (v_alignbyte + v_sad_u8), random content so that ties and edge clamps both occur."""
+    rng = np.random.default_rng(ctu)
+    cur = rng.integers(0, 4, (2, h, w), dtype=np.uint8) * 60
+    ref = rng.integers(0, 4, (2, h, w), dtype=np.uint8) * 60
+    a = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, rng_, method="brute"))
+    b = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, rng_, method="basic"))
+    np.testing.assert_array_equal(a, b)

@@ -168,7 +168,7 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
     method: "brute" = x265amd_me_fullsearch (every candidate's SAD), "sea" =
     x265amd_me_fullsearch_sea (exact successive elimination, same result; CTU 64 only;
     `workspace` = uint8 CUDA tensor of me_workspace_bytes() or None to allocate one),
-    "auto" = "sea" where it applies."""
+    "auto" = "sea" where it applies; "basic" = the independent one-candidate-per-lane kernel (tests)."""
     cp, f, h, w, cs, cfs = _planes(cur, torch.uint8, "cur")
     _dev(ref, torch.uint8, "ref")
     if ref.dim() == 2:
@@ -181,8 +181,14 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
     nctu = (h // ctu) * (w // ctu) if ctu > 0 else 0
     if out is None:
         out = torch.empty((f, nrefs, max(nctu, 0), 2), dtype=torch.int32, device=cur.device)
-    if method not in ("auto", "brute", "sea"):
+    if method not in ("auto", "brute", "sea", "basic"):
         raise ValueError("method")
+    if method == "basic":  # the one-candidate-per-lane cross-check kernel (debug entry point, not in the header)
+        fn = _lib().x265amd_debug_me_fullsearch_basic
+        fn.restype, fn.argtypes = SIGNATURES["x265amd_me_fullsearch"]
+        _check(fn(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs, ref.stride(0) if f > 1 else 0, nrefs,
+                  ref.stride(1) if nrefs > 1 else 0, out.data_ptr(), _stream()), "x265amd_debug_me_fullsearch_basic")
+        return out
     use_sea = method == "sea" or (method == "auto" and ctu == 64 and w > 0 and h > 0 and w % 64 == 0 and h % 64 == 0)
     if use_sea:
         need = me_workspace_bytes(w, h, search_range, f, nrefs)

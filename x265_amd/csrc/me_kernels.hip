@@ -156,20 +156,21 @@ __global__ __launch_bounds__(256) void me_fullsearch_basic(const MeParams p)
 // partial sums are widened to u32 every 4 rows (64 * 1020 < 65536).
 // Winner = min over (sad << 32 | raster index) by wave shuffles.
 // ---------------------------------------------------------------------------
+template <int B>  // block size: 64 (CTU), 32 or 16 (PU sizes); B / 4 dwords per row
 __global__ __launch_bounds__(256, 2) void me_fullsearch_qsad(const uint8_t *__restrict__ cur_base,
                                                              const uint8_t *__restrict__ ref_base,
                                                              x265amd_mv *__restrict__ out, const MeGeom g)
 {
-    constexpr int T = kMeT;
+    constexpr int T = kMeT, DW = B / 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *win = smem;
     const int tid = threadIdx.x;
     const int ctx = blockIdx.x, cty = blockIdx.y;
     const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
-    const int cx = ctx * 64, cy = cty * 64;
+    const int cx = ctx * B, cy = cty * B;
     const int R = g.range;
     int dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows;
-    me_qsad_layout(g.width, g.height, R, cx, cy, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows);
+    me_qsad_layout(g.width, g.height, R, cx, cy, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows, B);
     const uint8_t *cur = cur_base + f * g.cur_fs;
     const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
 
@@ -201,29 +202,30 @@ __global__ __launch_bounds__(256, 2) void me_fullsearch_qsad(const uint8_t *__re
 #pragma unroll
             for (int j = 0; j < 4; j++) acc32[t][j] = 0;
         }
-        uint32_t S[T][16];  // sliding window of T current rows, SGPRs
-        for (int m = 0; m < (64 + T - 1 + T - 1) / T; m++) {
+        uint32_t S[T][DW];  // sliding window of T current rows, SGPRs
+#pragma unroll 1  // one T-row step per trip: unrolled further the 32x32 instance spills
+        for (int m = 0; m < (B + T - 1 + T - 1) / T; m++) {
 #pragma unroll
             for (int j = 0; j < T; j++) {
                 const int rho = T * m + j;  // reference row of the tile == newest current row
-                if (rho < 64) {
+                if (rho < B) {
 #pragma unroll
-                    for (int k = 0; k < 16; k++) S[j][k] = cbase[rho * cstr + k];
+                    for (int k = 0; k < DW; k++) S[j][k] = cbase[rho * cstr + k];
                 }
-                if (rho < 64 + T - 1) {
+                if (rho < B + T - 1) {
                     const uint32_t *p = wrow + rho * pitch;
-                    uint64_t pr[16];
+                    uint64_t pr[DW];
 #pragma unroll
-                    for (int k = 0; k < 16; k++) pr[k] = ((uint64_t)p[k + 1] << 32) | p[k];
+                    for (int k = 0; k < DW; k++) pr[k] = ((uint64_t)p[k + 1] << 32) | p[k];
 #pragma unroll
                     for (int t = 0; t < T; t++) {
                         const int r = rho - t;  // current row paired with this reference row for dy offset t
-                        if (r >= 0 && r < 64) {
+                        if (r >= 0 && r < B) {
                             const int sj = (j - t + T) % T;
 #pragma unroll
-                            for (int k = 0; k < 16; k++)
+                            for (int k = 0; k < DW; k++)
                                 acc16[t] = __builtin_amdgcn_qsad_pk_u16_u8(pr[k], S[sj][k], acc16[t]);
-                            if ((r & 3) == 3) {  // 4 rows * 16 qsads * 1020 < 2^16: widen before it can wrap
+                            if ((r & 3) == 3) {  // 4 rows * B/4 qsads * 1020 < 2^16: widen before it can wrap
 #pragma unroll
                                 for (int q = 0; q < 4; q++) acc32[t][q] += (uint32_t)(acc16[t] >> (16 * q)) & 0xffffu;
                                 acc16[t] = 0;
@@ -302,38 +304,61 @@ extern "C" int x265amd_me_fullsearch(const uint8_t *d_cur, const uint8_t *d_ref,
     if (nframes == 0) return X265AMD_OK;
     if ((int64_t)nframes * nrefs > 65535) return X265AMD_ERR_ARG;
 
-    if (ctu == 64) {
+    {
         MeGeom g;
         g.width = width;
         g.height = height;
         g.stride = stride;
         g.range = range;
         g.nrefs = nrefs;
-        g.ctus_x = width / 64;
-        g.ctus_y = height / 64;
+        g.ctus_x = width / ctu;
+        g.ctus_y = height / ctu;
         g.cur_fs = cur_frame_stride;
         g.ref_fs = ref_frame_stride;
         g.ref_rs = ref_ref_stride;
-        // window rows depend on the CTU row only, the pitch on the CTU column only
+        // window rows depend on the block row only, the pitch on the block column only
         int max_rows = 0, max_pitch = 0;
         int dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows;
-        for (int cy = 0; cy < height; cy += 64) {
-            me_qsad_layout(width, height, range, 0, cy, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows);
+        for (int cy = 0; cy < height; cy += ctu) {
+            me_qsad_layout(width, height, range, 0, cy, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows, ctu);
             max_rows = win_rows > max_rows ? win_rows : max_rows;
         }
-        for (int cx = 0; cx < width; cx += 64) {
-            me_qsad_layout(width, height, range, cx, 0, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows);
+        for (int cx = 0; cx < width; cx += ctu) {
+            me_qsad_layout(width, height, range, cx, 0, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows, ctu);
             max_pitch = pitch > max_pitch ? pitch : max_pitch;
         }
         const size_t lds = (size_t)max_rows * max_pitch * 4;
         if (lds + 64 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;
-        X265AMD_HIP(hipFuncSetAttribute((const void *)me_fullsearch_qsad, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds));
-        hipLaunchKernelGGL(me_fullsearch_qsad, dim3(g.ctus_x, g.ctus_y, nframes * nrefs), dim3(256), lds,
-                           (hipStream_t)stream, d_cur, d_ref, d_out, g);
+        const dim3 grid(g.ctus_x, g.ctus_y, nframes * nrefs);
+        const void *fn = ctu == 64 ? (const void *)me_fullsearch_qsad<64>
+                                   : ctu == 32 ? (const void *)me_fullsearch_qsad<32> : (const void *)me_fullsearch_qsad<16>;
+        X265AMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (ctu == 64)
+            hipLaunchKernelGGL(me_fullsearch_qsad<64>, grid, dim3(256), lds, (hipStream_t)stream, d_cur, d_ref, d_out, g);
+        else if (ctu == 32)
+            hipLaunchKernelGGL(me_fullsearch_qsad<32>, grid, dim3(256), lds, (hipStream_t)stream, d_cur, d_ref, d_out, g);
+        else
+            hipLaunchKernelGGL(me_fullsearch_qsad<16>, grid, dim3(256), lds, (hipStream_t)stream, d_cur, d_ref, d_out, g);
         return hip_status(hipGetLastError());
     }
+}
 
+// The one-candidate-per-lane formulation (v_alignbyte_b32 + v_sad_u8, current block in LDS): an independent
+// cross-check of the production kernel, reachable through the debug entry point below only.
+extern "C" int x265amd_debug_me_fullsearch_basic(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
+                                                 int stride, int ctu, int range, int nframes, int64_t cur_frame_stride,
+                                                 int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride,
+                                                 x265amd_mv *d_out, void *stream)
+{
+    if (!initialised()) return X265AMD_ERR_NOT_INIT;
+    if (!d_cur || !d_ref || !d_out) return X265AMD_ERR_ARG;
+    if (ctu != 16 && ctu != 32 && ctu != 64) return X265AMD_ERR_ARG;
+    if (width <= 0 || height <= 0 || width % ctu || height % ctu || stride < width) return X265AMD_ERR_ARG;
+    if (range < 0 || range > 1024 || nframes <= 0 || nrefs < 1) return X265AMD_ERR_ARG;
+    if ((stride & 3) || ((uintptr_t)d_cur & 3) || ((uintptr_t)d_ref & 3) || (cur_frame_stride & 3) ||
+        (ref_frame_stride & 3) || (ref_ref_stride & 3))
+        return X265AMD_ERR_ARG;
+    if ((int64_t)nframes * nrefs > 65535) return X265AMD_ERR_ARG;
     MeParams p;
     p.cur = d_cur;
     p.ref = d_ref;
