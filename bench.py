@@ -263,8 +263,9 @@ def main():
                 break
             acc += np.array(buf[:])
         lib.x265amd_debug_me_timing(0)
-        kernels_ms = dict(zip(["box16_h", "box16_v", "sea_bounds_kernel", "sea_exact_kernel"],
+        kernels_ms = dict(zip(["box16_pairs", "_", "sea_bounds_kernel", "sea_exact_kernel"],
                               [round(float(x) / reps, 4) for x in acc]))
+        kernels_ms.pop("_", None)
 
     if rank == 0:
         px_step = nw * nh * fps                      # nominal pixels (1920x1080), SURVEY.md 8d
@@ -305,7 +306,7 @@ def main():
                                    f"full search, {nrefs} ref(s), then {tu}x{tu} DCT+quant+recon QP{qp}; "
                                    f"{fps} frames per step per GPU, frames sharded across GPUs, no collective",
                        "name": args.workload, "frames_per_step_per_gpu": fps, "me_method": pipe.method},
-            "roofline": {"kernel": "search stage = box16_h + box16_v + sea_bounds_kernel + sea_exact_kernel (dominant)"
+            "roofline": {"kernel": "search stage = box16_pairs + sea_bounds_kernel + sea_exact_kernel (dominant)"
                                    if pipe.method == "sea" else "me_fullsearch_qsad",
                          "bound": "hbm", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),

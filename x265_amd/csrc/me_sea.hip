@@ -27,67 +27,81 @@
 namespace x265amd {
 
 // ------------------------------------------------------------------ box sums
-// horizontal: H16[y][x] = sum_{k<16} p[y][x+k]; a thread makes 4 consecutive x from 5 aligned dwords
-__global__ __launch_bounds__(256) void box16_h(const uint8_t *__restrict__ ref_base, uint16_t *__restrict__ hbuf,
-                                               int width, int height, int stride, int nrefs, int64_t ref_fs,
-                                               int64_t ref_rs, uint32_t *__restrict__ ctrl)
+// P[y][x] = B16[y][x] | B16[y][x + 16] << 16, where B16[y][x] = sum of the 16x16 reference block at (x, y)
+// (u16: 16 * 16 * 255 < 2^16).  The two sub-blocks of one candidate that sit side by side share a dword,
+// so that one v_sad_u16 adds both |differences| to the candidate's bound.
+//
+// One kernel, one pass over the picture: a workgroup makes a 112 x 64 tile of P.  (1) horizontal 16-sums
+// H16 of the 128 columns x 79 rows the tile needs, 4 outputs per item from 5 dwords of pixels, into LDS;
+// (2) vertical running sums down the columns -- a thread owns a column pair (packed u16) and a quarter of
+// the rows -- into LDS; (3) pairs out, 8 bytes per lane.  HBM: 1.5 B/px read, 4 B/px written (two kernels
+// with H16 in memory moved 9.5 B/px).
+constexpr int kBoxTW = 112, kBoxTH = 64;   // tile of P
+constexpr int kBoxCols = kBoxTW + 16;      // B16 / H16 columns per tile: 64 pairs = one per thread and quarter
+constexpr int kBoxRows = kBoxTH + 15;      // H16 rows per tile
+constexpr int kBoxPitch = 136;             // u16 per LDS row: 272 B, a multiple of 8
+__global__ __launch_bounds__(256) void box16_pairs(const uint8_t *__restrict__ ref_base, uint32_t *__restrict__ pbuf,
+                                                   int width, int height, int stride, int nrefs, int64_t ref_fs,
+                                                   int64_t ref_rs, uint32_t *__restrict__ ctrl)
 {
+    __shared__ __attribute__((aligned(16))) uint16_t Ht[kBoxRows][kBoxPitch];
+    __shared__ __attribute__((aligned(16))) uint16_t Bt[kBoxTH][kBoxPitch];
     // the queue counters of the later kernels start from zero (stream order: this grid ends first)
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) ctrl[threadIdx.x] = 0;
-    const int xq = blockIdx.x * 256 + threadIdx.x;  // group of 4 pixels
-    const int y = blockIdx.y;
-    const int pl = blockIdx.z;
-    const int f = pl / nrefs, r = pl - f * nrefs;
-    if (4 * xq >= width) return;
-    const uint8_t *row = ref_base + f * ref_fs + r * ref_rs + (int64_t)y * stride;
-    uint32_t d[5];
-#pragma unroll
-    for (int i = 0; i < 5; i++) d[i] = (4 * (xq + i) + 4 <= width) ? *reinterpret_cast<const uint32_t *>(row + 4 * (xq + i)) : 0u;
-    uint32_t s0 = __builtin_amdgcn_sad_u8(d[0], 0u, 0u);
-    s0 = __builtin_amdgcn_sad_u8(d[1], 0u, s0);
-    s0 = __builtin_amdgcn_sad_u8(d[2], 0u, s0);
-    s0 = __builtin_amdgcn_sad_u8(d[3], 0u, s0);
-    const uint32_t s1 = s0 - (d[0] & 255u) + (d[4] & 255u);
-    const uint32_t s2 = s1 - ((d[0] >> 8) & 255u) + ((d[4] >> 8) & 255u);
-    const uint32_t s3 = s2 - ((d[0] >> 16) & 255u) + ((d[4] >> 16) & 255u);
-    uint2 o;
-    o.x = s0 | (s1 << 16);
-    o.y = s2 | (s3 << 16);
-    *reinterpret_cast<uint2 *>(hbuf + ((int64_t)pl * height + y) * width + 4 * xq) = o;
-}
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * kBoxTW, y0 = blockIdx.y * kBoxTH, pl = blockIdx.z;
+    const int f = pl / nrefs, r_ = pl - f * nrefs;
+    const uint8_t *ref = ref_base + f * ref_fs + r_ * ref_rs;
 
-// vertical: B16[y][x] = sum_{k<16} H16[y+k][x], written as PAIRS P[y][x] = B16[y][x] | B16[y][x+16] << 16:
-// the two sub-blocks of one candidate that sit side by side share a dword, so that one v_sad_u16
-// adds both |differences| to the candidate's bound.  A thread owns columns 2xp, 2xp+1 and their
-// partners 16 to the right (packed u16 pairs) and a run of rows.
-constexpr int kBoxVRows = 64;
-__global__ __launch_bounds__(256) void box16_v(const uint16_t *__restrict__ hbuf, uint32_t *__restrict__ pbuf, int width,
-                                               int height)
-{
-    const int xp = blockIdx.x * 256 + threadIdx.x;  // pair of columns
-    const int y0 = blockIdx.y * kBoxVRows;
-    const int pl = blockIdx.z;
-    if (2 * xp >= width) return;
-    const int wp = width >> 1;
-    const bool far_ok = xp + 8 < wp;  // partner columns inside the plane (else no legal candidate uses them)
-    const uint32_t *hn = reinterpret_cast<const uint32_t *>(hbuf + (int64_t)pl * height * width) + xp;
-    const uint32_t *hf = hn + (far_ok ? 8 : 0);
-    uint2 *p = reinterpret_cast<uint2 *>(pbuf + (int64_t)pl * height * width) + xp;
-    if (y0 + 16 > height) return;
-    uint32_t an = 0, af = 0;  // two u16 sums each; 16 * 4080 < 2^16, so the packed adds never carry across
+    // (1) H16[r][c] = sum_{k<16} p[y0 + r][x0 + c + k]; pixels outside the picture count as 0 (sums that
+    //     include them belong to sub-blocks no legal candidate uses)
+    for (int i = tid; i < kBoxRows * (kBoxCols / 4); i += 256) {
+        const int r = i / (kBoxCols / 4), gq = i - r * (kBoxCols / 4);
+        const int y = y0 + r, x = x0 + 4 * gq;
+        uint32_t d[5];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        an += hn[(int64_t)(y0 + k) * wp];
-        af += hf[(int64_t)(y0 + k) * wp];
+        for (int k = 0; k < 5; k++)
+            d[k] = (y < height && x + 4 * k + 4 <= width) ? *reinterpret_cast<const uint32_t *>(ref + (int64_t)y * stride + x + 4 * k) : 0u;
+        uint32_t s0 = __builtin_amdgcn_sad_u8(d[0], 0u, 0u);
+        s0 = __builtin_amdgcn_sad_u8(d[1], 0u, s0);
+        s0 = __builtin_amdgcn_sad_u8(d[2], 0u, s0);
+        s0 = __builtin_amdgcn_sad_u8(d[3], 0u, s0);
+        const uint32_t s1 = s0 - (d[0] & 255u) + (d[4] & 255u);
+        const uint32_t s2 = s1 - ((d[0] >> 8) & 255u) + ((d[4] >> 8) & 255u);
+        const uint32_t s3 = s2 - ((d[0] >> 16) & 255u) + ((d[4] >> 16) & 255u);
+        *reinterpret_cast<uint2 *>(&Ht[r][4 * gq]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
     }
-    p[(int64_t)y0 * wp] = make_uint2((an & 0xffffu) | (af << 16), (an >> 16) | (af & 0xffff0000u));
-#pragma unroll 8
-    for (int y = y0 + 1; y < y0 + kBoxVRows && y + 16 <= height; y++) {
-        // packed u16 pair: take the old row out first (each half contains it: no borrow), then the
-        // new row in (each half <= 16 * 4080 < 2^16: no carry)
-        an = (an - hn[(int64_t)(y - 1) * wp]) + hn[(int64_t)(y + 15) * wp];
-        af = (af - hf[(int64_t)(y - 1) * wp]) + hf[(int64_t)(y + 15) * wp];
-        p[(int64_t)y * wp] = make_uint2((an & 0xffffu) | (af << 16), (an >> 16) | (af & 0xffff0000u));
+    __syncthreads();
+
+    // (2) B16[r][c] = sum_{j<16} H16[r + j][c]: packed u16 pairs; 16 * 4080 < 2^16, so the packed adds never
+    //     carry across, and the old row is taken out before the new one goes in (no borrow either)
+    {
+        const int cp = tid & 63, q = tid >> 6;  // column pair, quarter of the tile's rows
+        constexpr int pd = kBoxPitch / 2;       // LDS pitch in dwords
+        const uint32_t *h = reinterpret_cast<const uint32_t *>(&Ht[0][0]) + cp;
+        uint32_t *bt = reinterpret_cast<uint32_t *>(&Bt[0][0]) + cp;
+        const int rb = 16 * q;
+        uint32_t acc = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc += h[(rb + k) * pd];
+        bt[rb * pd] = acc;
+#pragma unroll
+        for (int j = 1; j < 16; j++) {
+            acc = (acc - h[(rb + j - 1) * pd]) + h[(rb + j + 15) * pd];
+            bt[(rb + j) * pd] = acc;
+        }
+    }
+    __syncthreads();
+
+    // (3) pairs out: P[y][x] = B16[y][x] | B16[y][x + 16] << 16, two columns (8 bytes) per item
+    for (int i = tid; i < kBoxTH * (kBoxTW / 2); i += 256) {
+        const int r = i / (kBoxTW / 2), c = i - r * (kBoxTW / 2);
+        const int y = y0 + r, x = x0 + 2 * c;
+        if (y + 16 > height || x + 2 > width) continue;
+        const uint32_t an = *reinterpret_cast<const uint32_t *>(&Bt[r][2 * c]);
+        const uint32_t af = *reinterpret_cast<const uint32_t *>(&Bt[r][2 * c + 16]);
+        *reinterpret_cast<uint2 *>(pbuf + ((int64_t)pl * height + y) * width + x) =
+            make_uint2((an & 0xffffu) | (af << 16), (an >> 16) | (af & 0xffff0000u));
     }
 }
 
@@ -799,7 +813,7 @@ extern "C" int x265amd_debug_me_timing(int enable)
     g_me_timing = enable != 0;
     return X265AMD_OK;
 }
-// ms of box16_h, box16_v, sea_bounds_kernel, sea_exact_kernel of the last timed call (waits for it)
+// ms of box16_pairs, (nothing), sea_bounds_kernel, sea_exact_kernel of the last timed call (waits for it)
 extern "C" int x265amd_debug_me_last_ms(float *out4)
 {
     if (!g_me_ev[0] || !out4) return X265AMD_ERR_ARG;
@@ -833,7 +847,7 @@ extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, i
     sea_extents(width, height, range, max_rows, max_pitch, max_ngx, max_ndy);
     const size_t planes = (size_t)nframes * nrefs, nctu = (size_t)(width / 64) * (height / 64);
     const size_t per_ctu = ((size_t)max_ngx * max_ndy + 7) & ~(size_t)7;  // 16-byte rows
-    return align256(6 * (size_t)width * height * planes)                    // H16 (u16) + pair plane (u32) per (frame, ref) plane
+    return align256(4 * (size_t)width * height * planes)                    // pair plane (u32) per (frame, ref) plane
            + 2 * align256(sizeof(uint16_t) * per_ctu * nctu * planes)      // bounds + first-batch list per CTU
            + align256(sizeof(SeaHdr) * nctu * planes)
            + align256(sizeof(uint32_t) * kClasses * nctu * planes)         // launch-order queues of the exact kernel
@@ -916,9 +930,8 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
 
     const size_t nctu = (size_t)(width / 64) * (height / 64);
     uint8_t *ws = (uint8_t *)d_workspace;
-    uint32_t *pbuf = (uint32_t *)ws;  // pair plane first (16-byte loads), H16 behind it
-    uint16_t *hbuf = (uint16_t *)(pbuf + (size_t)nplanes * width * height);
-    ws += align256(6 * (size_t)width * height * (size_t)nplanes);
+    uint32_t *pbuf = (uint32_t *)ws;  // pair plane (16-byte loads)
+    ws += align256(4 * (size_t)width * height * (size_t)nplanes);
     uint16_t *gl = (uint16_t *)ws;
     ws += align256(sizeof(uint16_t) * (size_t)gl_pitch * nctu * (size_t)nplanes);
     uint16_t *list0 = (uint16_t *)ws;
@@ -934,11 +947,9 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     hipStream_t st = (hipStream_t)stream;
     const bool timing = g_me_timing;
     if (timing) (void)hipEventRecord(g_me_ev[0], st);
-    hipLaunchKernelGGL(box16_h, dim3((width / 4 + 255) / 256, height, (unsigned)nplanes), dim3(256), 0, st, d_ref, hbuf,
-                       width, height, stride, nrefs, ref_frame_stride, ref_ref_stride, ctrl);
+    hipLaunchKernelGGL(box16_pairs, dim3((width + kBoxTW - 1) / kBoxTW, (height - 15 + kBoxTH - 1) / kBoxTH, (unsigned)nplanes),
+                       dim3(256), 0, st, d_ref, pbuf, width, height, stride, nrefs, ref_frame_stride, ref_ref_stride, ctrl);
     if (timing) (void)hipEventRecord(g_me_ev[1], st);
-    hipLaunchKernelGGL(box16_v, dim3((width / 2 + 255) / 256, (height + kBoxVRows - 1) / kBoxVRows, (unsigned)nplanes),
-                       dim3(256), 0, st, hbuf, pbuf, width, height);
     if (timing) (void)hipEventRecord(g_me_ev[2], st);
     MeGeom g;
     g.width = width;
