@@ -11,14 +11,14 @@
 // 64-bit key (sad << 32 | raster index) over what was evaluated -- the
 // reference's "first strict minimum" (src/encode.cpp:762-765).
 //
-// Four kernels:
-//   box16_h / box16_v : B16[y][x] = sum of the 16x16 reference block at (x, y), u16
-//                       (16*16*255 < 2^16), separable, coalesced, HBM-bound;
-//   sea_bounds_kernel : per (CTU, ref, frame) workgroup, small LDS, high occupancy -- bounds for
-//                       every legal candidate (v_sad_u32 against the CTU's own sub-block
-//                       sums), histogram pick of a first batch;
-//   sea_exact_kernel  : window to LDS, exact SADs of the first batch, then of everything
-//                       whose bound is still <= best.
+// Three kernels:
+//   box16_pairs       : P[y][x] = B16[y][x] | B16[y][x+16] << 16, B16 = sum of the 16x16 reference block at
+//                       (x, y) (u16): horizontal sums, vertical running sums and pairing in one tiled pass;
+//   sea_bounds_kernel : per (CTU, ref, frame) workgroup, small LDS -- bounds of every group of four
+//                       candidates (v_sad_u16 on the pair plane against the CTU's own sub-block sums),
+//                       histogram pick of a first batch, an exact-SAD probe for the work estimate;
+//   sea_exact_kernel  : persistent workgroups, longest CTUs first: window to LDS, exact SADs of the first
+//                       batch, then of everything whose bound is still <= best.
 #include <stdlib.h>
 
 #include "common.h"
@@ -153,7 +153,7 @@ struct SeaHdr {  // per (plane, CTU)
 };
 constexpr int kFirst = 256;   // first batch: two rounds of 128 groups
 constexpr int kMaxWgLists = 512;  // persistent workgroups that may need a schedule slice in the workspace
-constexpr int kClasses = 4;   // launch-order classes (kClasses + 1 <= 8 counters: box16_h zeroes 8) of the work estimate, heaviest first
+constexpr int kClasses = 4;   // launch-order classes (kClasses + 1 <= 8 counters: box16_pairs zeroes 8) of the work estimate, heaviest first
 __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est >= 1024 ? 1 : est >= 850 ? 2 : 3; }
 
 // ---------------------------------------------------------------------------------------------
