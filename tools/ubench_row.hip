@@ -83,6 +83,84 @@ template <int LDS, int SLOAD, int WAVES, int PACKED = 0> static void run(const c
            per_row, 100.0 * 258.0 / per_row);
 }
 
+// Two dy per lane: window row r pairs with current row r (candidate dy) and r-1 (candidate dy+1); the
+// LDS row and the s_load are paid once per 32 qsads.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k2(uint32_t *__restrict__ out, const uint32_t *__restrict__ cur, int cstr,
+                                                 uint32_t seed, int pitch)
+{
+    __shared__ uint32_t win[200 * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 200 * PITCH; i += WAVES * 64) win[i] = i * 2654435761u + seed;
+    __syncthreads();
+    uint32_t acc32[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+    uint32_t dA[17], dB[17], S0[16], S1[16], S2[16];
+    const uint64_t c0 = clock64();
+    for (int blk = 0; blk < BLOCKS; blk++) {
+        const uint32_t *wrow = win + (lane & 31) + ((lane >> 5) + (wave & 3) + (blk & 63)) * pitch;
+        const uint32_t *crow = cur + (wave & 3) * 16 * cstr;
+        uint64_t a0 = 0, a1 = 0;
+#define LD_W(r, d) { const uint32_t *p_ = wrow + (r) * pitch; _Pragma("unroll") for (int k2 = 0; k2 < 17; k2++) d[k2] = p_[k2]; }
+#define LD_C(r, S) { _Pragma("unroll") for (int k2 = 0; k2 < 16; k2++) S[k2] = crow[(r) * cstr + k2]; }
+#define ROW2(d, Sa, Sb)                                                                                      \
+    _Pragma("unroll") for (int k2 = 0; k2 < 16; k2++) {                                                     \
+        const uint64_t x_ = ((uint64_t)d[k2 + 1] << 32) | d[k2];                                             \
+        a0 = __builtin_amdgcn_qsad_pk_u16_u8(x_, Sa[k2], a0);                                                \
+        a1 = __builtin_amdgcn_qsad_pk_u16_u8(x_, Sb[k2], a1);                                                \
+    }
+#define FLUSH()                                                                                              \
+    { _Pragma("unroll") for (int q = 0; q < 4; q++) { acc32[q] += (uint32_t)(a0 >> (16 * q)) & 0xffffu; acc32[4 + q] += (uint32_t)(a1 >> (16 * q)) & 0xffffu; } a0 = a1 = 0; }
+        LD_W(0, dA) LD_C(0, S0) LD_C(1, S1)
+        // rows in triples so that the three current-row buffers rotate with static names
+#pragma unroll
+        for (int r = 0; r < 15; r += 3) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            LD_W(r + 1, dB) LD_C(r + 2, S2)
+            __builtin_amdgcn_sched_barrier(0);
+            ROW2(dA, S1, S0)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            LD_W(r + 2, dA) LD_C(r + 3, S0)
+            __builtin_amdgcn_sched_barrier(0);
+            ROW2(dB, S2, S1)
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            LD_W(r + 3, dB) LD_C(r + 4, S1)
+            __builtin_amdgcn_sched_barrier(0);
+            ROW2(dA, S0, S2)
+            __builtin_amdgcn_sched_barrier(0);
+            FLUSH()
+#pragma unroll
+            for (int k2 = 0; k2 < 17; k2++) dA[k2] = dB[k2];
+        }
+#undef LD_W
+#undef LD_C
+#undef ROW2
+#undef FLUSH
+    }
+    const uint64_t c1 = clock64();
+    uint32_t a = 0;
+    for (int q = 0; q < 8; q++) a ^= acc32[q];
+    if (a == 0x12345678u) out[tid] = a;
+    if (blockIdx.x == 7 && lane == 0) ((uint64_t *)out)[512 + wave] = c1 - c0;
+}
+
+template <int WAVES> static void run2(const char *name, uint32_t *d_out, uint32_t *d_cur, int pitch)
+{
+    uint64_t h[16];
+    for (int rep = 0; rep < 2; rep++)
+        hipLaunchKernelGGL((k2<WAVES>), dim3(256), dim3(WAVES * 64), 0, 0, d_out, d_cur, 480, 1u + rep, pitch);
+    hipDeviceSynchronize();
+    hipMemcpy(h, (uint64_t *)d_out + 512, sizeof(h), hipMemcpyDeviceToHost);
+    uint64_t mx = 0;
+    for (int i = 0; i < WAVES; i++) mx = h[i] > mx ? h[i] : mx;
+    // 15 window rows x 32 qsads per block = 30 row-equivalents of 16 qsads
+    const double per_row = (double)mx / (BLOCKS * 30) / (WAVES / 4);
+    printf("%-44s %2d waves/CU: %6.1f SIMD cycles per 16 qsads (258 at the issue limit: %4.1f %%)\n", name, WAVES, per_row,
+           100.0 * 258.0 / per_row);
+}
+
 int main()
 {
     uint32_t *d_out, *d_cur;
@@ -97,5 +175,7 @@ int main()
     run<1, 1, 8, 1>("same, current block packed (immediate offsets)", d_out, d_cur, PITCH);
     run<1, 1, 16, 1>("same, current block packed (immediate offsets)", d_out, d_cur, PITCH);
     run<1, 1, 4>("qsad + LDS row + s_load", d_out, d_cur, PITCH);
+    run2<8>("two dy per lane (32 qsads per window row)", d_out, d_cur, PITCH);
+    run2<16>("two dy per lane (32 qsads per window row)", d_out, d_cur, PITCH);
     return 0;
 }
