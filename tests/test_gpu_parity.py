@@ -436,3 +436,24 @@ def test_me_production_kernel_equals_basic_formulation(gpu, ctu, rng_, w, h):
     a = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, rng_, method="brute"))
     b = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, rng_, method="basic"))
     np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("method", ["sea", "brute"])
+def test_pipeline_multi_reference_negative_stride(gpu, oracle, method):
+    """MeTqPipeline with 2 references: ref(f, r) = frame (f - 1 - r), handed to the C-ABI as a NEGATIVE
+    byte stride between references (no copies).  Vectors per (frame, ref) against the oracle; the
+    transform stage uses reference 0."""
+    from x265_amd import synth, MeTqPipeline
+    W, H, R, NR, F = 192, 128, 12, 2, 3
+    seq = synth.make_sequence(W, H, F + NR, search_range=R, seed=77)
+    pipe = MeTqPipeline(dev(seq), ctu=64, search_range=R, nrefs=NR, tu=32, qp=27, method=method)
+    pipe.step()
+    got = gpu.mv_to_numpy(pipe.mv)
+    for f in range(F):
+        for r in range(NR):
+            want = oracle.me_fullsearch(seq[NR + f], seq[NR + f - 1 - r], 64, R, nthreads=8)
+            np.testing.assert_array_equal(got[f, r], want, f"frame {f} ref {r}")
+        lvl, sums = oracle.tq_forward(seq[NR + f], seq[NR + f - 1], 32, 27, 1, mv=got[f, 0], mv_ctu=64)
+        rec = oracle.tq_inverse(lvl, seq[NR + f - 1], 32, 27, 1, mv=got[f, 0], mv_ctu=64)
+        np.testing.assert_array_equal(host(pipe.level)[f], lvl)
+        np.testing.assert_array_equal(host(pipe.rec)[f], rec)
