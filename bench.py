@@ -43,6 +43,7 @@ WORKLOADS = {
     "4k": (3840, 2160, 64, 128, 1, 4, 32, 32),        # configs[3]: one GOP segment of 4 per step
     "8k4ref": (7680, 4320, 64, 64, 4, 2, 32, 32),     # configs[4]
     "tq1080p": (1920, 1080, 64, 0, 1, 16, 32, 32),    # configs[2]: transform/quant only (see --tu), no search
+    "gop1080p": (1920, 1080, 64, 64, 1, 16, 32, 32),  # closed-loop P pictures, 16 GOP segments, 4:2:0
 }
 
 
@@ -174,6 +175,59 @@ def tq_only(args, world, rank, backend, nw, nh, ctu, fps, tu, qp):
         dist.destroy_process_group()
 
 
+def closed_loop(args, world, rank, backend, nw, nh, rng, nseg, qp):
+    """Closed-loop P pictures (x265_amd.ClosedLoopGop): `nseg` independent GOP segments advance one picture per
+    step -- search against the previous RECONSTRUCTION, luma 32x32 + chroma 16x16 transform / quant /
+    reconstruction, reference rotation.  Pixels counted: luma of the nominal picture, like the main metric."""
+    import torch.distributed as dist
+    from x265_amd import ClosedLoopGop
+    T = 4
+    w, h = nw, (nh + 63) // 64 * 64
+    segs = []
+    for s_ in range(nseg):
+        y, u, v = synth.make_sequence(w, h, T, search_range=rng, seed=12345 + 1000 * rank + s_, chroma=True)
+        segs.append(np.concatenate([y.reshape(T, -1), u.reshape(T, -1), v.reshape(T, -1)], axis=1))
+    yuv = torch.from_numpy(np.stack(segs)).cuda()          # [S][T][W*H*3/2]
+    enc = ClosedLoopGop(w, h, nseg, search_range=rng, qp=qp)
+    enc.set_reference(yuv[:, 0].contiguous())
+    pics = [yuv[:, t].contiguous() for t in range(1, T)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    k = 0
+    for _ in range(args.warmup):
+        enc.encode_p(pics[k % len(pics)])
+        k += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.encode_p(pics[k % len(pics)])
+        k += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "closed-loop ME+TQ Mpixels/s", "value": round(nw * nh * nseg * world * args.steps / elapsed / 1e6, 2),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{nw}x{nh} 4:2:0 (padded {w}x{h}), closed loop: {nseg} GOP segments per GPU advance one P "
+                                   f"picture per step; +-{rng} search on the previous reconstruction, luma 32x32 and chroma "
+                                   f"16x16 TQ + reconstruction QP{qp}, reference rotation", "name": args.workload,
+                       "me_method": enc.method},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -212,6 +266,8 @@ def main():
     tu = args.tu or tu
     if args.workload == "tq1080p":
         return tq_only(args, world, rank, backend, nw, nh, ctu, fps, tu, qp)
+    if args.workload == "gop1080p":
+        return closed_loop(args, world, rank, backend, nw, nh, rng, fps, qp)
     frames_np = make_frames(nw, nh, ctu, rng, fps + nrefs, seed=12345 + 1000 * rank)
     h, w = frames_np.shape[1:]
     frames = torch.from_numpy(frames_np).cuda()
