@@ -197,6 +197,11 @@ int x265amd_tq_forward(const x265amd_tq_desc *desc, void *stream);
  * reconstructs to the prediction exactly as the memcpy branch there does). */
 int x265amd_tq_inverse(const x265amd_tq_desc *desc, void *stream);
 
+/* xIDctAdd alone (inc/x265.h:296, src/pixel.cpp:724-776): as x265amd_tq_inverse, but d_level holds
+ * DEQUANTISED coefficients (xDeQuant's output) and qp is ignored -- the reconstruction stage on its
+ * own, for stage-by-stage checks like the reference's CHECK_TV blocks. */
+int x265amd_idct_add(const x265amd_tq_desc *desc, void *stream);
+
 /* forward + inverse in one pass over the picture (the whole "Stage 3a/3b" of
  * src/encode.cpp:863-925): writes level, abs_sum and rec without the
  * coefficient round trip through HBM. */

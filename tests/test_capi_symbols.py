@@ -9,10 +9,10 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "x265_amd.h")).read()
+def declared_symbols(header="x265_amd.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(x265amd_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(x265amd_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_the_path():
@@ -30,6 +30,32 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/x265_amd.h but not exported"
     assert sorted(api.SIGNATURES) == declared_symbols(), "python binding table out of sync with the header"
+
+
+def test_library_exports_every_dropin_symbol():
+    """include/x265_amd_dropin.h: one entry per slot of xSadN[] / xDctN[] / xInvDctN[] and per free function of
+    the reference's pixel layer (inc/x265.h:290-298)."""
+    from x265_amd import api
+    syms = declared_symbols("x265_amd_dropin.h")
+    assert len(syms) == 1 + 5 + 10 + 4
+    lib = C.CDLL(api.LIB_PATH)
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in include/x265_amd_dropin.h but not exported"
+    assert sorted(api.DROPIN_SIGNATURES) == syms
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["x265_amd.h", "x265_amd_dropin.h"]
+
+
+def test_dropins_report_errors_without_gpu():
+    """No device / not initialised: nothing is written, the status says why, nothing aborts."""
+    import numpy as np
+    from x265_amd import api
+    lib = api.load_library()
+    a = np.zeros((8, 8), np.uint8)
+    r = lib.x265amd_xSad8xN(8, a.ctypes.data, 8, a.ctypes.data, 8)
+    if lib.x265amd_dropin_status() != 0:       # on the GPU box after init this call simply works
+        assert r == 0xFFFFFFFF
+    r = lib.x265amd_xSad8xN(65, a.ctypes.data, 8, a.ctypes.data, 8)   # more rows than a CU has
+    assert r == 0xFFFFFFFF and lib.x265amd_dropin_status() == -1
 
 
 def test_host_side_helpers_without_gpu():

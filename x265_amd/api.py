@@ -68,11 +68,27 @@ SIGNATURES = {
                                              C.c_void_p, C.c_size_t, C.c_void_p]),
     "x265amd_tq_forward": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
     "x265amd_tq_inverse": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
+    "x265amd_idct_add": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
     "x265amd_tq_roundtrip": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
     "x265amd_quant_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_int, C.c_void_p, C.c_void_p]),
     "x265amd_dequant_plane": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_void_p]),
+}
+
+# include/x265_amd_dropin.h: the reference's own per-block signatures (inc/x265.h:290-298), host pointers
+_SAD = (C.c_uint32, [C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint])
+_DCT = (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int])
+_BLK = (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint])
+DROPIN_SIGNATURES = {
+    "x265amd_dropin_status": (C.c_int, []),
+    **{f"x265amd_xSad{w}xN": _SAD for w in (4, 8, 16, 32, 64)},
+    **{f"x265amd_{n}": _DCT for n in ("xDST4", "xDCT4", "xDCT8", "xDCT16", "xDCT32",
+                                       "xInvDST4", "xInvDCT4", "xInvDCT8", "xInvDCT16", "xInvDCT32")},
+    "x265amd_xSubDct": _BLK,
+    "x265amd_xIDctAdd": _BLK,
+    "x265amd_xQuant": (C.c_uint32, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
+    "x265amd_xDeQuant": (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_int, C.c_int, C.c_int]),
 }
 
 
@@ -84,7 +100,7 @@ def _lib():
                 f"{LIB_PATH} is missing: build it with `make -C x265_amd/csrc` "
                 "(or __graft_entry__.build()).  There is no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in {**SIGNATURES, **DROPIN_SIGNATURES}.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
@@ -297,6 +313,14 @@ def tq_inverse(level, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, mode
     d = _tq_desc(tu, qp, slice_type, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level, rec=rec,
                  pred_origin=pred_origin, mv_shift=mv_shift)
     _check(_lib().x265amd_tq_inverse(C.byref(d), _stream()), "x265amd_tq_inverse")
+    return rec
+
+
+def idct_add(coef, pred, tu, modes=None, pred_origin=(0, 0)):
+    """xIDctAdd alone over whole planes: `coef` holds dequantised coefficients.  Returns rec."""
+    rec = _alloc_like(coef, torch.uint8)
+    d = _tq_desc(tu, 0, SLICE_I, pred=pred, modes=modes, level=coef, rec=rec, pred_origin=pred_origin)
+    _check(_lib().x265amd_idct_add(C.byref(d), _stream()), "x265amd_idct_add")
     return rec
 
 

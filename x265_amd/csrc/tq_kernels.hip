@@ -402,7 +402,7 @@ static void quant_constants(int tu, int qp, int slice_type, TqParams &p)
     p.dq_scale = kInvQuantScales[qp % 6] << (qp / 6);
 }
 
-template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_t stream)
+template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_t stream, bool coef_in = false)
 {
     if (!initialised()) return X265AMD_ERR_NOT_INIT;
     if (!desc) return X265AMD_ERR_ARG;
@@ -428,6 +428,11 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     if (nt > 0x7fffffff) return X265AMD_ERR_ARG;
     p.ntiles = (int)nt;
     quant_constants(d.tu, d.qp, d.slice_type, p);
+    if (coef_in) {  // the plane already holds xDeQuant's output: (c * 1 + 0) >> 0, and the clip is a no-op on Int16
+        p.dq_scale = 1;
+        p.dq_rnd = 0;
+        p.dq_shift = 0;
+    }
     const dim3 grid((unsigned)((nt + 7) / 8)), block(256);
     switch (d.tu) {
     case 4: hipLaunchKernelGGL((tq_kernel<4, MODE>), grid, block, 0, stream, p); break;
@@ -449,6 +454,10 @@ extern "C" int x265amd_tq_forward(const x265amd_tq_desc *desc, void *stream)
 extern "C" int x265amd_tq_inverse(const x265amd_tq_desc *desc, void *stream)
 {
     return launch_tq<TQ_INV>(desc, (hipStream_t)stream);
+}
+extern "C" int x265amd_idct_add(const x265amd_tq_desc *desc, void *stream)
+{
+    return launch_tq<TQ_INV>(desc, (hipStream_t)stream, true);
 }
 extern "C" int x265amd_tq_roundtrip(const x265amd_tq_desc *desc, void *stream)
 {
