@@ -36,6 +36,8 @@ extern "C" {
 #endif
 
 int x265amd_dropin_status(void);
+/* number of drop-in calls served by the GPU (status ok) since the library was loaded */
+uint64_t x265amd_dropin_calls(void);
 
 /* xSadN[0..4] = xSad4xN .. xSad64xN (typedef xSad inc/x265.h:290; src/pixel.cpp:30-101) */
 uint32_t x265amd_xSad4xN(const unsigned N, const uint8_t *pSrc, const unsigned nStrideSrc, const uint8_t *pRef, const unsigned nStrideRef);

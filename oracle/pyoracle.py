@@ -192,6 +192,18 @@ class Reference(_Lib):
         f.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.POINTER(C.c_int32),
                       _u8p, _u8p, C.c_int]
 
+    def get_tables(self):
+        """Current contents of xSadN[], xDctN[], xInvDctN[] as three lists of 5 addresses."""
+        arrs = [(C.c_void_p * 5)() for _ in range(3)]
+        self.lib.ref_tables_get(*arrs)
+        return [list(a) for a in arrs]
+
+    def set_tables(self, sad=None, dct=None, inv=None):
+        """Overwrite the reference's mutable plug-in tables (src/pixel.cpp:95,571,579) with function
+        addresses; None entries keep what is there."""
+        args = [None if t is None else (C.c_void_p * 5)(*t) for t in (sad, dct, inv)]
+        self.lib.ref_tables_set(*args)
+
     def tq_frame(self, src, pred, n, qp, slice_type, mv=None, mv_ctu=64, modes=None):
         h, w = src.shape
         level = np.zeros((h, w), np.int16)

@@ -67,6 +67,27 @@ void ref_dequant(int16_t *dst, int16_t *src, unsigned stride, unsigned qp, int w
     xDeQuant(dst, src, stride, qp, w, h, (X265_SliceType)st);
 }
 
+/* The reference's plug-in points are three MUTABLE global tables (src/pixel.cpp:95,571,579).  Tests point
+ * them at other implementations with the same signatures -- the GPU drop-ins of
+ * include/x265_amd_dropin.h -- and then run the reference's own encoder over them.
+ * get: copy the current 5+5+5 pointers out; set: NULL arrays / NULL entries keep the current ones. */
+void ref_tables_get(void **sad5, void **dct5, void **inv5)
+{
+    for (int i = 0; i < 5; i++) {
+        sad5[i] = (void *)xSadN[i];
+        dct5[i] = (void *)xDctN[i];
+        inv5[i] = (void *)xInvDctN[i];
+    }
+}
+void ref_tables_set(void *const *sad5, void *const *dct5, void *const *inv5)
+{
+    for (int i = 0; i < 5; i++) {
+        if (sad5 && sad5[i]) xSadN[i] = (xSad *)sad5[i];
+        if (dct5 && dct5[i]) xDctN[i] = (xDCT *)dct5[i];
+        if (inv5 && inv5[i]) xInvDctN[i] = (xDCT *)inv5[i];
+    }
+}
+
 /* Exhaustive search over the reference's xSadN[] with the reference's argmin
  * idiom (src/encode.cpp:725-727,762-765). */
 void ref_me_fullsearch(const uint8_t *cur, const uint8_t *ref, int width, int height, int stride,

@@ -37,7 +37,7 @@ def test_library_exports_every_dropin_symbol():
     the reference's pixel layer (inc/x265.h:290-298)."""
     from x265_amd import api
     syms = declared_symbols("x265_amd_dropin.h")
-    assert len(syms) == 1 + 5 + 10 + 4
+    assert len(syms) == 2 + 5 + 10 + 4
     lib = C.CDLL(api.LIB_PATH)
     for name in syms:
         assert hasattr(lib, name), f"{name} declared in include/x265_amd_dropin.h but not exported"

@@ -161,3 +161,43 @@ def test_dropin_rejects_what_the_reference_asserts_on(dropin, gpu):
     with pytest.raises(X265AmdError):
         dropin.xSadN[0](0, a, 4, a, 4)
     assert dropin.xSadN[4](64, a, 64, a, 64) == 0        # and the layer still works afterwards
+
+
+def test_reference_encoder_over_gpu_pixel_tables(gpu, reference):
+    """The drop-in claim end to end: the REAL reference encoder (oracle/_ref, compiled from the reference's
+    sources) with its three mutable plug-in tables xSadN[] / xDctN[] / xInvDctN[] (src/pixel.cpp:95,571,579)
+    pointed at the GPU drop-ins encodes BASELINE configs[0]'s first frames to the same bitstream sizes and
+    the same reconstruction MD5s as the committed fixture of the all-CPU run.  Every SAD of the intra mode
+    decision and every 1-D transform pass of xSubDct / xIDctAdd goes through the GPU, one block per call."""
+    import ctypes as C
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from x265_amd import api, synth
+    lib = api.load_library()
+    addr = lambda name: C.cast(getattr(lib, name), C.c_void_p).value
+    sad = [addr(f"x265amd_xSad{w}xN") for w in (4, 8, 16, 32, 64)]
+    dct = [addr("x265amd_" + n) for n in ("xDST4", "xDCT4", "xDCT8", "xDCT16", "xDCT32")]
+    inv = [addr("x265amd_" + n) for n in ("xInvDST4", "xInvDCT4", "xInvDCT8", "xInvDCT16", "xInvDCT32")]
+    with open(os.path.join(GOLDEN, "intra_cfg1.json")) as f:
+        doc = json.load(f)
+    nf = 2
+    yuv = synth.make_intra_probe(doc["width"], doc["height"], doc["frames"])[:nf].copy()
+    saved = reference.get_tables()
+    calls0 = lib.x265amd_dropin_calls()
+    try:
+        reference.set_tables(sad, dct, inv)
+        assert reference.get_tables() == [sad, dct, inv]
+        rec, nbytes, md5, bs = reference.encode_intra(yuv, doc["width"], doc["height"], doc["cu"], doc["qp"])
+    finally:
+        reference.set_tables(*saved)
+    served = lib.x265amd_dropin_calls() - calls0
+    ncu = (doc["width"] // doc["cu"]) * (doc["height"] // doc["cu"])
+    assert served > nf * ncu * 20, f"only {served} calls reached the GPU"
+    assert lib.x265amd_dropin_status() == 0
+    assert [int(x) for x in nbytes] == doc["bytes_per_frame"][:nf]
+    assert [bytes(m).hex() for m in md5] == doc["recon_md5"][:nf]
+    # and the tables are the reference's own again
+    cpu = reference.encode_intra(yuv[:1], doc["width"], doc["height"], doc["cu"], doc["qp"])
+    assert lib.x265amd_dropin_calls() - calls0 == served and bytes(cpu[2][0]).hex() == doc["recon_md5"][0]

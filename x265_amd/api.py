@@ -82,6 +82,7 @@ _DCT = (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int])
 _BLK = (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint])
 DROPIN_SIGNATURES = {
     "x265amd_dropin_status": (C.c_int, []),
+    "x265amd_dropin_calls": (C.c_uint64, []),
     **{f"x265amd_xSad{w}xN": _SAD for w in (4, 8, 16, 32, 64)},
     **{f"x265amd_{n}": _DCT for n in ("xDST4", "xDCT4", "xDCT8", "xDCT16", "xDCT32",
                                        "xInvDST4", "xInvDCT4", "xInvDCT8", "xInvDCT16", "xInvDCT32")},

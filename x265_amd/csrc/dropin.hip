@@ -4,6 +4,7 @@
 // in a small device buffer, runs the SAME kernels the batched entry points run and copies the
 // result back -- a launch and two copies per block, so this layer is for bring-up and stage-by-stage
 // checking; the batched entry points of x265_amd.h are the product.  No CPU arithmetic in here.
+#include <atomic>
 #include <mutex>
 
 #include "../../include/x265_amd_dropin.h"
@@ -62,6 +63,7 @@ struct Stage {  // device-side staging of one block
 std::mutex g_mu;
 Stage *g_stage = nullptr;
 thread_local int t_status = X265AMD_OK;
+std::atomic<uint64_t> g_calls{0};  // calls that reached the GPU and came back ok
 
 int stage_ready()
 {
@@ -196,13 +198,20 @@ int dequant(int16_t *dst, const int16_t *src, unsigned stride, unsigned qp, int 
 using namespace x265amd;
 
 extern "C" int x265amd_dropin_status(void) { return t_status; }
+extern "C" uint64_t x265amd_dropin_calls(void) { return g_calls.load(); }
+
+static int served(int status)
+{
+    if (status == X265AMD_OK) g_calls++;
+    return status;
+}
 
 #define DROPIN_SAD(W)                                                                                         \
     extern "C" uint32_t x265amd_xSad##W##xN(const unsigned N, const uint8_t *pSrc, const unsigned nStrideSrc,  \
                                             const uint8_t *pRef, const unsigned nStrideRef)                   \
     {                                                                                                         \
         uint32_t v = 0xffffffffu;                                                                             \
-        t_status = sad(W, N, pSrc, nStrideSrc, pRef, nStrideRef, &v);                                         \
+        t_status = served(sad(W, N, pSrc, nStrideSrc, pRef, nStrideRef, &v));                                        \
         return t_status == X265AMD_OK ? v : 0xffffffffu;                                                      \
     }
 DROPIN_SAD(4)
@@ -214,7 +223,7 @@ DROPIN_SAD(64)
 #define DROPIN_1D(NAME, N, INV, DST)                                                                      \
     extern "C" void x265amd_##NAME(int16_t *pDst, int16_t *pSrc, unsigned nStride, int nLines, int nShift) \
     {                                                                                                     \
-        t_status = pass1d<N, INV, DST>(pDst, pSrc, nStride, nLines, nShift);                              \
+        t_status = served(pass1d<N, INV, DST>(pDst, pSrc, nStride, nLines, nShift));                         \
     }
 DROPIN_1D(xDST4, 4, false, true)
 DROPIN_1D(xDCT4, 4, false, false)
@@ -232,7 +241,7 @@ extern "C" void x265amd_xSubDct(int16_t *pDst, uint8_t *pSrc, uint8_t *pRef, uns
 {
     (void)piTmp0;  // the reference's scratch: the intermediate never leaves the chip here
     (void)piTmp1;
-    t_status = sub_dct(pDst, pSrc, pRef, nStride, iWidth, iHeight, nMode);
+    t_status = served(sub_dct(pDst, pSrc, pRef, nStride, iWidth, iHeight, nMode));
 }
 
 extern "C" void x265amd_xIDctAdd(uint8_t *pDst, int16_t *pSrc, uint8_t *pRef, unsigned nStride, int16_t *piTmp0,
@@ -240,14 +249,14 @@ extern "C" void x265amd_xIDctAdd(uint8_t *pDst, int16_t *pSrc, uint8_t *pRef, un
 {
     (void)piTmp0;
     (void)piTmp1;
-    t_status = idct_add(pDst, pSrc, pRef, nStride, iWidth, iHeight, nMode);
+    t_status = served(idct_add(pDst, pSrc, pRef, nStride, iWidth, iHeight, nMode));
 }
 
 extern "C" uint32_t x265amd_xQuant(int16_t *pDst, int16_t *pSrc, unsigned nStride, unsigned nQP, int iWidth,
                                    int iHeight, int eSType)
 {
     uint32_t sum = 0;
-    t_status = quant(pDst, pSrc, nStride, nQP, iWidth, iHeight, eSType, &sum);
+    t_status = served(quant(pDst, pSrc, nStride, nQP, iWidth, iHeight, eSType, &sum));
     return t_status == X265AMD_OK ? sum : 0;
 }
 
@@ -255,5 +264,5 @@ extern "C" void x265amd_xDeQuant(int16_t *pDst, int16_t *pSrc, unsigned nStride,
                                  int iHeight, int eSType)
 {
     (void)eSType;  // unused by the reference too (src/pixel.cpp:635-651)
-    t_status = dequant(pDst, pSrc, nStride, nQP, iWidth, iHeight);
+    t_status = served(dequant(pDst, pSrc, nStride, nQP, iWidth, iHeight));
 }
