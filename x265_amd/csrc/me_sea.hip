@@ -737,25 +737,35 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     int n1 = 0;
     const uint32_t best_sad = (uint32_t)(best_key >> 32);
     if (rest_min != kNone && (rest_min << 4) <= best_sad) {
-        // sweep 1 counts the wave's takers, ONE LDS atomic reserves their slots, sweep 2 fills them in scan order
-        int wcount = 0;
-        for (int g0 = 0; g0 < L.ngroups; g0 += kThreads) {
-            const int gi = g0 + tid;
-            const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
-            wcount += (int)__popcll(__ballot(v != kNone && (v << 4) <= best_sad));
-        }
-        int wbase = 0;
-        if (lane == 0 && wcount) wbase = atomicAdd(&list_n, wcount);
-        wbase = __builtin_amdgcn_readfirstlane(wbase);
-        if (wcount) {
-            for (int g0 = 0; g0 < L.ngroups; g0 += kThreads) {
-                const int gi = g0 + tid;
-                const uint32_t v = gi < L.ngroups ? (uint32_t)glo[gi] : kNone;
-                const bool take = v != kNone && (v << 4) <= best_sad;
-                const unsigned long long tm = __ballot(take);
-                if (take) list[wbase + (int)__popcll(tm & ((1ull << lane) - 1ull))] = (uint16_t)gi;
-                wbase += (int)__popcll(tm);
+        // one sweep: a thread takes 8 consecutive bounds (one 16-byte load, all of a CTU's loads in flight at
+        // once), a wave scan ranks the takers, ONE LDS atomic per wave reserves their slots
+        const int nvec = (L.ngroups + 7) >> 3;  // gl rows are 16-byte aligned and padded to a multiple of 8
+        for (int v0 = 0; v0 < nvec; v0 += kThreads) {
+            const int vi = v0 + tid;
+            uint4 wv = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            if (vi < nvec) wv = reinterpret_cast<const uint4 *>(glo)[vi];
+            const uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
+            uint32_t tm = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const uint32_t v = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+                if (8 * vi + e < L.ngroups && v != kNone && (v << 4) <= best_sad) tm |= 1u << e;
             }
+            const int cnt = __popc(tm);
+            int inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+            }
+            const int tot = __shfl(inc, 63);
+            if (tot == 0) continue;  // wave-uniform
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&list_n, tot);
+            int slot = __shfl(wbase, 0) + inc - cnt;
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (tm & (1u << e)) list[slot++] = (uint16_t)(8 * vi + e);
         }
         __syncthreads();
         n1 = list_n;
