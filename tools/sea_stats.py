@@ -31,6 +31,10 @@ interior = [i for i in range(nctu_all) if 2 <= (i % nctu) % (W // 64) <= W // 64
 print("interior CTUs:", {n: float(s[interior, i].mean()) for i, n in enumerate(names)})
 print("CTUs with a second pass:", int((s[:, 1] > 0).sum()), "of", nctu_all,
       "| rounds per CTU (mean):", float((np.ceil(s[:, 0] / 128) + np.ceil(s[:, 1] / 128)).mean()))
+print("pass-1 sizes, fine (1-4, 5-8, 9-16, 17-32, 33-64):",
+      [int(((s[:, 1] >= a) & (s[:, 1] <= b)).sum()) for a, b in ((1, 4), (5, 8), (9, 16), (17, 32), (33, 64))],
+      "| mean pass-1 cycles in those buckets:",
+      [int(s[(s[:, 1] >= a) & (s[:, 1] <= b), 4].mean()) if ((s[:, 1] >= a) & (s[:, 1] <= b)).any() else 0 for a, b in ((1, 4), (5, 8), (9, 16), (17, 32), (33, 64))])
 print("pass-1 sizes histogram (0, 1-64, 65-128, 129-512, >512):",
       [int(((s[:, 1] >= a) & (s[:, 1] <= b)).sum()) for a, b in ((0, 0), (1, 64), (65, 128), (129, 512), (513, 1 << 30))])
 
