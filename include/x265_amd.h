@@ -97,6 +97,16 @@ int x265amd_sad_blocks(int w, int n, const uint8_t *d_src, int stride_src, const
                        int stride_ref, const uint32_t *d_src_off, const uint32_t *d_ref_off,
                        int nblocks, uint32_t *d_out, void *stream);
 
+/* Batched SATD with the calling convention of x265amd_sad_blocks.  The reference has NO SATD
+ * (SURVEY.md 8a row a14); BASELINE.json's north_star names it as a primitive of the search.  Definition:
+ * the HEVC test model's (TComRdCost::xCalcHADs8x8 / xCalcHADs4x4) -- per 8x8 sub-block
+ * (sum |H8 D H8^T| + 2) >> 2; blocks 4 wide or 4 high use 4x4 sub-blocks, (sum |H4 D H4^T| + 1) >> 1.
+ * PARITY UNPINNED: checked against this repo's own CPU restatement and closed-form cases only.
+ * w, n in {4, 8, 16, 32, 64}. */
+int x265amd_satd_blocks(int w, int n, const uint8_t *d_src, int stride_src, const uint8_t *d_ref,
+                        int stride_ref, const uint32_t *d_src_off, const uint32_t *d_ref_off,
+                        int nblocks, uint32_t *d_out, void *stream);
+
 /* ---------------------------------------------------------- motion search */
 
 /* Exhaustive integer-pel search, one vector per ctu x ctu block (SURVEY.md

@@ -154,6 +154,13 @@ class Oracle(_Lib):
         f.restype = None
         f.argtypes = [_i16p, C.c_int, _u8p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                       C.c_int, C.c_int, _u8p, _u8p, C.c_int, C.c_int]
+        f = self.lib.orc_satd
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_int, C.c_int, _u8p, C.c_int, _u8p, C.c_int]
+
+    def satd(self, w, n, src, ss, ref, sr):
+        """SATD, HM definition -- not in the reference: PARITY UNPINNED (x265_oracle.c)."""
+        return self.lib.orc_satd(w, n, _p(_chk(src, np.uint8), _u8p), ss, _p(_chk(ref, np.uint8), _u8p), sr)
 
     def tq_forward(self, src, pred, n, qp, slice_type, mv=None, mv_ctu=64, modes=None, nthreads=1):
         h, w = src.shape

@@ -86,6 +86,45 @@ uint32_t orc_sad(int w, int n, const uint8_t *src, int ss, const uint8_t *ref, i
     return sad;
 }
 
+/* ------------------------------------------------------------------------ */
+/* SATD.  NOT in the reference: PARITY UNPINNED.  The   */
+/* definition is the HEVC test model's (TComRdCost::xCalcHADs8x8 / 4x4),      */
+/* restated as the matrix product it is: H[i][k] = (-1)^popcount(i & k);      */
+/* 8x8 sub-blocks (sum |H D H^T| + 2) >> 2; 4x4 sub-blocks, used when the     */
+/* block is 4 wide or 4 high, (sum |H D H^T| + 1) >> 1.                       */
+/* ------------------------------------------------------------------------ */
+static int had_sign(int i, int k) { return __builtin_popcount((unsigned)(i & k)) & 1 ? -1 : 1; }
+
+static uint32_t satd_sub(int m, const uint8_t *s, int ss, const uint8_t *r, int sr)
+{
+    int d[8][8], t[8][8];
+    for (int y = 0; y < m; y++)
+        for (int x = 0; x < m; x++) d[y][x] = (int)s[(size_t)y * ss + x] - (int)r[(size_t)y * sr + x];
+    for (int i = 0; i < m; i++) /* t = H d */
+        for (int x = 0; x < m; x++) {
+            int a = 0;
+            for (int k = 0; k < m; k++) a += had_sign(i, k) * d[k][x];
+            t[i][x] = a;
+        }
+    uint32_t sum = 0;
+    for (int i = 0; i < m; i++) /* |t H^T| */
+        for (int j = 0; j < m; j++) {
+            int a = 0;
+            for (int k = 0; k < m; k++) a += t[i][k] * had_sign(j, k);
+            sum += (uint32_t)abs(a);
+        }
+    return m == 8 ? (sum + 2) >> 2 : (sum + 1) >> 1;
+}
+
+uint32_t orc_satd(int w, int n, const uint8_t *src, int ss, const uint8_t *ref, int sr)
+{
+    const int m = (w == 4 || n == 4) ? 4 : 8;
+    uint32_t satd = 0;
+    for (int y = 0; y < n; y += m)
+        for (int x = 0; x < w; x += m) satd += satd_sub(m, src + (size_t)y * ss + x, ss, ref + (size_t)y * sr + x, sr);
+    return satd;
+}
+
 static uint32_t sad64x64(const uint8_t *src, int ss, const uint8_t *ref, int sr)
 {
     uint32_t sad = 0;

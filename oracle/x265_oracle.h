@@ -43,6 +43,8 @@ int orc_chroma_qp(int qp); /* g_aucChromaScale, src/table.cpp:166-171 */
 
 /* xSad{4,8,16,32,64}xN: src/pixel.cpp:30-93 */
 uint32_t orc_sad(int w, int n, const uint8_t *src, int ss, const uint8_t *ref, int sr);
+/* SATD, HM definition; the reference has none -- PARITY UNPINNED (see x265_oracle.c) */
+uint32_t orc_satd(int w, int n, const uint8_t *src, int ss, const uint8_t *ref, int sr);
 
 /* xDctN[idx] / xInvDctN[idx]: src/pixel.cpp:114-312,321-569,571-585.
  * idx: 0=DST4 1=DCT4 2=DCT8 3=DCT16 4=DCT32 (same table order). */

@@ -59,6 +59,8 @@ SIGNATURES = {
     "x265amd_chroma_qp": (C.c_int, [C.c_int]),
     "x265amd_sad_blocks": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "x265amd_satd_blocks": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "x265amd_me_fullsearch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
@@ -167,6 +169,20 @@ def sad_blocks(w, n, src, stride_src, ref, stride_ref, src_off, ref_off):
     _check(_lib().x265amd_sad_blocks(w, n, src.data_ptr(), stride_src, ref.data_ptr(), stride_ref,
                                      src_off.data_ptr(), ref_off.data_ptr(), nb, out.data_ptr(), _stream()),
            "x265amd_sad_blocks")
+    return out
+
+
+def satd_blocks(w, n, src, stride_src, ref, stride_ref, src_off, ref_off):
+    """Batched SATD (HM definition; not in the reference, parity unpinned) with sad_blocks' convention."""
+    _dev(src, torch.uint8, "src"), _dev(ref, torch.uint8, "ref")
+    _dev(src_off, torch.int32, "src_off"), _dev(ref_off, torch.int32, "ref_off")
+    nb = src_off.numel()
+    if ref_off.numel() != nb:
+        raise ValueError("src_off / ref_off length mismatch")
+    out = torch.empty(nb, dtype=torch.int32, device=src.device)
+    _check(_lib().x265amd_satd_blocks(w, n, src.data_ptr(), stride_src, ref.data_ptr(), stride_ref,
+                                      src_off.data_ptr(), ref_off.data_ptr(), nb, out.data_ptr(), _stream()),
+           "x265amd_satd_blocks")
     return out
 
 
