@@ -166,8 +166,8 @@ def test_dropin_rejects_what_the_reference_asserts_on(dropin, gpu):
 def test_reference_encoder_over_gpu_pixel_tables(gpu, reference):
     """The drop-in claim end to end: the REAL reference encoder (oracle/_ref, compiled from the reference's
     sources) with its three mutable plug-in tables xSadN[] / xDctN[] / xInvDctN[] (src/pixel.cpp:95,571,579)
-    pointed at the GPU drop-ins encodes BASELINE configs[0]'s first frames to the same bitstream sizes and
-    the same reconstruction MD5s as the committed fixture of the all-CPU run.  Every SAD of the intra mode
+    pointed at the GPU drop-ins encodes BASELINE configs[0] (all 8 frames) to the same bitstream, byte for
+    byte (MD5 of the stream), and the same reconstruction MD5s as the committed fixture of the all-CPU run.  Every SAD of the intra mode
     decision and every 1-D transform pass of xSubDct / xIDctAdd goes through the GPU, one block per call."""
     import ctypes as C
     import json
@@ -182,8 +182,9 @@ def test_reference_encoder_over_gpu_pixel_tables(gpu, reference):
     inv = [addr("x265amd_" + n) for n in ("xInvDST4", "xInvDCT4", "xInvDCT8", "xInvDCT16", "xInvDCT32")]
     with open(os.path.join(GOLDEN, "intra_cfg1.json")) as f:
         doc = json.load(f)
-    nf = 2
-    yuv = synth.make_intra_probe(doc["width"], doc["height"], doc["frames"])[:nf].copy()
+    import hashlib
+    nf = doc["frames"]
+    yuv = synth.make_intra_probe(doc["width"], doc["height"], nf)
     saved = reference.get_tables()
     calls0 = lib.x265amd_dropin_calls()
     try:
@@ -198,6 +199,7 @@ def test_reference_encoder_over_gpu_pixel_tables(gpu, reference):
     assert lib.x265amd_dropin_status() == 0
     assert [int(x) for x in nbytes] == doc["bytes_per_frame"][:nf]
     assert [bytes(m).hex() for m in md5] == doc["recon_md5"][:nf]
+    assert hashlib.md5(bs.tobytes()).hexdigest() == doc["bitstream_md5"]
     # and the tables are the reference's own again
     cpu = reference.encode_intra(yuv[:1], doc["width"], doc["height"], doc["cu"], doc["qp"])
     assert lib.x265amd_dropin_calls() - calls0 == served and bytes(cpu[2][0]).hex() == doc["recon_md5"][0]
