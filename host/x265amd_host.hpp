@@ -1,0 +1,175 @@
+// x265amd_host.hpp -- C++ host side of the MI355X ME + transform/quant path, above the C-ABI only.
+//
+// What the reference's encode.cpp would hold for P pictures if it had them (src/encode.cpp:581-584 is
+// `assert(0)`): the frame / reference bookkeeping of xEncEncode (refn[] ring and its rotation,
+// src/encode.cpp:619-621, 965-970; frame layout Y,U,V in one W*H*3/2 block, stride = width,
+// src/encode.cpp:41-45), one search launch and three transform/quant launches per picture.  Needs nothing
+// but include/x265_amd.h and libx265amd.so: no HIP headers, no torch.  (x265_amd/pipeline.py is the same
+// loop in Python for the tests and the bench.)
+#pragma once
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <memory>
+#include <utility>
+#include <vector>
+
+#include "x265_amd.h"
+
+namespace x265amd_host {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const char *where)
+        : std::runtime_error(std::string(where) + ": " + x265amd_strerror(st) + " (status " + std::to_string(st) + ")"),
+          status(st)
+    {
+    }
+};
+inline void check(int st, const char *where)
+{
+    if (st != X265AMD_OK) throw Error(st, where);
+}
+
+class DeviceBuffer {  // xEncInit's MALLOC / xEncFree's FREE (src/encode.cpp:40-46, 54-62), on the device
+  public:
+    explicit DeviceBuffer(size_t bytes) : bytes_(bytes) { check(x265amd_malloc(&p_, bytes ? bytes : 16), "x265amd_malloc"); }
+    ~DeviceBuffer() { x265amd_free(p_); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    template <class T = uint8_t> T *as(size_t byte_off = 0) const { return reinterpret_cast<T *>(static_cast<uint8_t *>(p_) + byte_off); }
+    size_t bytes() const { return bytes_; }
+
+  private:
+    void *p_ = nullptr;
+    size_t bytes_;
+};
+
+// Closed-loop P pictures for `nseg` independent GOP segments (the unit that shards across GPUs): picture t
+// of every segment goes down in one launch per kernel.  Luma: 64x64 CTU search on the previous
+// reconstruction, 32x32 TUs.  Chroma 4:2:0: the luma vector >> 1, 16x16 TUs at g_aucChromaScale[qp].
+class GopEncoder {
+  public:
+    static constexpr int kMaxRefNum = 1;  // MAX_REF_NUM, inc/config.h
+
+    GopEncoder(int width, int height, int nseg, int range, int qp, int device = 0)
+        : w_(width), h_(height), nseg_(nseg), range_(range), qp_(qp)
+    {
+        if (width <= 0 || height <= 0 || width % 64 || height % 64 || nseg < 1)  // src/params.cpp:73-83 exit()s
+            throw Error(X265AMD_ERR_ARG, "GopEncoder: width and height must be multiples of the 64x64 CTU");
+        check(x265amd_init(device), "x265amd_init");
+        qpc_ = x265amd_chroma_qp(qp);
+        if (qpc_ < 0) throw Error(qpc_, "x265amd_chroma_qp");
+        ysz_ = (size_t)width * height;
+        csz_ = ysz_ / 4;
+        fsz_ = ysz_ + 2 * csz_;
+        nctu_ = (size_t)(width / 64) * (height / 64);
+        for (int i = 0; i <= kMaxRefNum; i++) refn_.emplace_back(new DeviceBuffer(fsz_ * nseg));
+        cur_.reset(new DeviceBuffer(fsz_ * nseg));
+        level_.reset(new DeviceBuffer(2 * fsz_ * nseg));
+        mv_.reset(new DeviceBuffer(sizeof(x265amd_mv) * nctu_ * nseg));
+        ntu_ = (size_t)(width / 32) * (height / 32);  // luma 32x32 TUs; the chroma planes have as many 16x16 TUs
+        cbf_.reset(new DeviceBuffer(4 * ntu_ * nseg * 3));
+        ws_bytes_ = x265amd_me_workspace_bytes(width, height, range, nseg, 1);
+        ws_.reset(new DeviceBuffer(ws_bytes_));
+    }
+
+    size_t frame_bytes() const { return fsz_; }
+    size_t ctus() const { return nctu_; }
+    size_t tus() const { return ntu_; }
+    int poc() const { return poc_; }
+    bool exhaustive_fallback() const { return brute_; }
+
+    // The reconstruction of each segment's I picture, made by the host (intra prediction is outside this path).
+    void set_reference(const uint8_t *yuv)
+    {
+        check(x265amd_memcpy_h2d(refn_[kMaxRefNum]->as(), yuv, fsz_ * nseg_, nullptr), "x265amd_memcpy_h2d");
+        poc_++;
+        rotate();
+    }
+
+    // One P picture per segment: yuv = nseg frames, Y,U,V each.  Asynchronous; fetch() waits.
+    void encode_p(const uint8_t *yuv)
+    {
+        check(x265amd_memcpy_h2d(cur_->as(), yuv, fsz_ * nseg_, nullptr), "x265amd_memcpy_h2d");
+        poc_++;
+        const uint8_t *src = cur_->as(), *ref = refn_[0]->as();
+        uint8_t *rec = refn_[kMaxRefNum]->as();
+        x265amd_mv *mv = mv_->as<x265amd_mv>();
+        if (!brute_) {
+            const int st = x265amd_me_fullsearch_sea(src, ref, w_, h_, w_, 64, range_, nseg_, (int64_t)fsz_, (int64_t)fsz_, 1, 0,
+                                                     mv, ws_->as(), ws_bytes_, nullptr);
+            if (st == X265AMD_ERR_LDS)
+                brute_ = true;  // window + schedule beyond the LDS: every-candidate kernel, same output
+            else
+                check(st, "x265amd_me_fullsearch_sea");
+        }
+        if (brute_)
+            check(x265amd_me_fullsearch(src, ref, w_, h_, w_, 64, range_, nseg_, (int64_t)fsz_, (int64_t)fsz_, 1, 0, mv, nullptr),
+                  "x265amd_me_fullsearch");
+        // Stage 3a/3b of src/encode.cpp:863-925 for the three planes
+        tq_plane(0, 0, w_, h_, 32, qp_, 64, 0);
+        tq_plane(ysz_, 1, w_ / 2, h_ / 2, 16, qpc_, 32, 1);
+        tq_plane(ysz_ + csz_, 2, w_ / 2, h_ / 2, 16, qpc_, 32, 1);
+        (void)rec;
+        rotate();  // src/encode.cpp:965-970: the new reconstruction becomes refn[0]
+    }
+
+    // Vectors [nseg][nctu], levels [nseg][W*H*3/2] (Y,U,V like the picture), reconstruction [nseg][W*H*3/2],
+    // per-TU sum|level| [3][nseg][ntu] (what sets bCbf, src/encode.cpp:888).  Null pointers are skipped.
+    void fetch(x265amd_mv *mv, int16_t *level, uint8_t *rec, uint32_t *abs_sum = nullptr)
+    {
+        if (mv) check(x265amd_memcpy_d2h(mv, mv_->as(), sizeof(x265amd_mv) * nctu_ * nseg_, nullptr), "x265amd_memcpy_d2h");
+        if (level) check(x265amd_memcpy_d2h(level, level_->as(), 2 * fsz_ * nseg_, nullptr), "x265amd_memcpy_d2h");
+        if (rec) check(x265amd_memcpy_d2h(rec, refn_[0]->as(), fsz_ * nseg_, nullptr), "x265amd_memcpy_d2h");
+        if (abs_sum) check(x265amd_memcpy_d2h(abs_sum, cbf_->as(), 4 * ntu_ * nseg_ * 3, nullptr), "x265amd_memcpy_d2h");
+        check(x265amd_stream_sync(nullptr), "x265amd_stream_sync");
+    }
+
+  private:
+    void rotate()
+    {
+        std::unique_ptr<DeviceBuffer> tmp = std::move(refn_[kMaxRefNum]);
+        for (int i = kMaxRefNum; i > 0; i--) refn_[i] = std::move(refn_[i - 1]);
+        refn_[0] = std::move(tmp);
+    }
+
+    void tq_plane(size_t off, int plane, int pw, int ph, int tu, int qp, int mv_ctu, int mv_shift)
+    {
+        x265amd_tq_desc t = {};
+        t.width = pw;
+        t.height = ph;
+        t.tu = tu;
+        t.qp = qp;
+        t.slice_type = X265AMD_SLICE_P;
+        t.nframes = nseg_;
+        t.d_src = cur_->as() + off;
+        t.src_stride = pw;
+        t.src_frame_stride = (int64_t)fsz_;
+        t.d_pred = refn_[0]->as() + off;  // the reference picture: motion compensation is fused into the load
+        t.pred_stride = pw;
+        t.pred_frame_stride = (int64_t)fsz_;
+        t.d_mv = mv_->as<x265amd_mv>();
+        t.mv_ctu = mv_ctu;
+        t.mv_frame_stride = (int64_t)nctu_;
+        t.mv_shift = mv_shift;
+        t.d_level = level_->as<int16_t>() + off;
+        t.level_stride = pw;
+        t.level_frame_stride = (int64_t)fsz_;
+        t.d_abs_sum = cbf_->as<uint32_t>() + (size_t)plane * ntu_ * nseg_;
+        t.abs_sum_frame_stride = (int64_t)ntu_;
+        t.d_rec = refn_[kMaxRefNum]->as() + off;
+        t.rec_stride = pw;
+        t.rec_frame_stride = (int64_t)fsz_;
+        check(x265amd_tq_roundtrip(&t, nullptr), "x265amd_tq_roundtrip");
+    }
+
+    int w_, h_, nseg_, range_, qp_, qpc_ = 0, poc_ = -1;
+    bool brute_ = false;
+    size_t ysz_ = 0, csz_ = 0, fsz_ = 0, nctu_ = 0, ntu_ = 0, ws_bytes_ = 0;
+    std::vector<std::unique_ptr<DeviceBuffer>> refn_;
+    std::unique_ptr<DeviceBuffer> cur_, level_, mv_, cbf_, ws_;
+};
+
+}  // namespace x265amd_host
