@@ -46,6 +46,20 @@ class DeviceBuffer {  // xEncInit's MALLOC / xEncFree's FREE (src/encode.cpp:40-
     size_t bytes_;
 };
 
+class PinnedBuffer {  // page-locked host memory for what crosses PCIe every picture
+  public:
+    explicit PinnedBuffer(size_t bytes) : bytes_(bytes) { check(x265amd_malloc_host(&p_, bytes ? bytes : 16), "x265amd_malloc_host"); }
+    ~PinnedBuffer() { x265amd_free_host(p_); }
+    PinnedBuffer(const PinnedBuffer &) = delete;
+    PinnedBuffer &operator=(const PinnedBuffer &) = delete;
+    template <class T = uint8_t> T *as() const { return static_cast<T *>(p_); }
+    size_t bytes() const { return bytes_; }
+
+  private:
+    void *p_ = nullptr;
+    size_t bytes_;
+};
+
 // Closed-loop P pictures for `nseg` independent GOP segments (the unit that shards across GPUs): picture t
 // of every segment goes down in one launch per kernel.  Luma: 64x64 CTU search on the previous
 // reconstruction, 32x32 TUs.  Chroma 4:2:0: the luma vector >> 1, 16x16 TUs at g_aucChromaScale[qp].
@@ -53,8 +67,10 @@ class GopEncoder {
   public:
     static constexpr int kMaxRefNum = 1;  // MAX_REF_NUM, inc/config.h
 
-    GopEncoder(int width, int height, int nseg, int range, int qp, int device = 0)
-        : w_(width), h_(height), nseg_(nseg), range_(range), qp_(qp)
+    // `stream`: a stream from x265amd_stream_create (nullptr = the default stream).  Encoders on different
+    // streams overlap: one's PCIe copies run under the other's kernels.
+    GopEncoder(int width, int height, int nseg, int range, int qp, int device = 0, void *stream = nullptr)
+        : w_(width), h_(height), nseg_(nseg), range_(range), qp_(qp), stream_(stream)
     {
         if (width <= 0 || height <= 0 || width % 64 || height % 64 || nseg < 1)  // src/params.cpp:73-83 exit()s
             throw Error(X265AMD_ERR_ARG, "GopEncoder: width and height must be multiples of the 64x64 CTU");
@@ -84,7 +100,7 @@ class GopEncoder {
     // The reconstruction of each segment's I picture, made by the host (intra prediction is outside this path).
     void set_reference(const uint8_t *yuv)
     {
-        check(x265amd_memcpy_h2d(refn_[kMaxRefNum]->as(), yuv, fsz_ * nseg_, nullptr), "x265amd_memcpy_h2d");
+        check(x265amd_memcpy_h2d(refn_[kMaxRefNum]->as(), yuv, fsz_ * nseg_, stream_), "x265amd_memcpy_h2d");
         poc_++;
         rotate();
     }
@@ -92,21 +108,21 @@ class GopEncoder {
     // One P picture per segment: yuv = nseg frames, Y,U,V each.  Asynchronous; fetch() waits.
     void encode_p(const uint8_t *yuv)
     {
-        check(x265amd_memcpy_h2d(cur_->as(), yuv, fsz_ * nseg_, nullptr), "x265amd_memcpy_h2d");
+        check(x265amd_memcpy_h2d(cur_->as(), yuv, fsz_ * nseg_, stream_), "x265amd_memcpy_h2d");
         poc_++;
         const uint8_t *src = cur_->as(), *ref = refn_[0]->as();
         uint8_t *rec = refn_[kMaxRefNum]->as();
         x265amd_mv *mv = mv_->as<x265amd_mv>();
         if (!brute_) {
             const int st = x265amd_me_fullsearch_sea(src, ref, w_, h_, w_, 64, range_, nseg_, (int64_t)fsz_, (int64_t)fsz_, 1, 0,
-                                                     mv, ws_->as(), ws_bytes_, nullptr);
+                                                     mv, ws_->as(), ws_bytes_, stream_);
             if (st == X265AMD_ERR_LDS)
                 brute_ = true;  // window + schedule beyond the LDS: every-candidate kernel, same output
             else
                 check(st, "x265amd_me_fullsearch_sea");
         }
         if (brute_)
-            check(x265amd_me_fullsearch(src, ref, w_, h_, w_, 64, range_, nseg_, (int64_t)fsz_, (int64_t)fsz_, 1, 0, mv, nullptr),
+            check(x265amd_me_fullsearch(src, ref, w_, h_, w_, 64, range_, nseg_, (int64_t)fsz_, (int64_t)fsz_, 1, 0, mv, stream_),
                   "x265amd_me_fullsearch");
         // Stage 3a/3b of src/encode.cpp:863-925 for the three planes
         tq_plane(0, 0, w_, h_, 32, qp_, 64, 0);
@@ -120,11 +136,17 @@ class GopEncoder {
     // per-TU sum|level| [3][nseg][ntu] (what sets bCbf, src/encode.cpp:888).  Null pointers are skipped.
     void fetch(x265amd_mv *mv, int16_t *level, uint8_t *rec, uint32_t *abs_sum = nullptr)
     {
-        if (mv) check(x265amd_memcpy_d2h(mv, mv_->as(), sizeof(x265amd_mv) * nctu_ * nseg_, nullptr), "x265amd_memcpy_d2h");
-        if (level) check(x265amd_memcpy_d2h(level, level_->as(), 2 * fsz_ * nseg_, nullptr), "x265amd_memcpy_d2h");
-        if (rec) check(x265amd_memcpy_d2h(rec, refn_[0]->as(), fsz_ * nseg_, nullptr), "x265amd_memcpy_d2h");
-        if (abs_sum) check(x265amd_memcpy_d2h(abs_sum, cbf_->as(), 4 * ntu_ * nseg_ * 3, nullptr), "x265amd_memcpy_d2h");
-        check(x265amd_stream_sync(nullptr), "x265amd_stream_sync");
+        fetch_async(mv, level, rec, abs_sum);
+        sync();
+    }
+    void sync() { check(x265amd_stream_sync(stream_), "x265amd_stream_sync"); }
+    // the copies only: valid after sync(); the host buffers should be pinned (PinnedBuffer) to be asynchronous
+    void fetch_async(x265amd_mv *mv, int16_t *level, uint8_t *rec, uint32_t *abs_sum = nullptr)
+    {
+        if (mv) check(x265amd_memcpy_d2h(mv, mv_->as(), sizeof(x265amd_mv) * nctu_ * nseg_, stream_), "x265amd_memcpy_d2h");
+        if (level) check(x265amd_memcpy_d2h(level, level_->as(), 2 * fsz_ * nseg_, stream_), "x265amd_memcpy_d2h");
+        if (rec) check(x265amd_memcpy_d2h(rec, refn_[0]->as(), fsz_ * nseg_, stream_), "x265amd_memcpy_d2h");
+        if (abs_sum) check(x265amd_memcpy_d2h(abs_sum, cbf_->as(), 4 * ntu_ * nseg_ * 3, stream_), "x265amd_memcpy_d2h");
     }
 
   private:
@@ -162,10 +184,11 @@ class GopEncoder {
         t.d_rec = refn_[kMaxRefNum]->as() + off;
         t.rec_stride = pw;
         t.rec_frame_stride = (int64_t)fsz_;
-        check(x265amd_tq_roundtrip(&t, nullptr), "x265amd_tq_roundtrip");
+        check(x265amd_tq_roundtrip(&t, stream_), "x265amd_tq_roundtrip");
     }
 
     int w_, h_, nseg_, range_, qp_, qpc_ = 0, poc_ = -1;
+    void *stream_ = nullptr;
     bool brute_ = false;
     size_t ysz_ = 0, csz_ = 0, fsz_ = 0, nctu_ = 0, ntu_ = 0, ws_bytes_ = 0;
     std::vector<std::unique_ptr<DeviceBuffer>> refn_;

@@ -78,9 +78,17 @@ const char *x265amd_strerror(int status);
  * (xEncInit's MALLOC of the frame buffers, src/encode.cpp:40-46; xEncFree :54-62). */
 int x265amd_malloc(void **d_ptr, size_t bytes);
 int x265amd_free(void *d_ptr);
+/* page-locked host memory for the buffers that cross PCIe every picture (source frames up; vectors, levels
+ * down): copies from / to it run at link speed and truly asynchronously */
+int x265amd_malloc_host(void **h_ptr, size_t bytes);
+int x265amd_free_host(void *h_ptr);
 int x265amd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int x265amd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int x265amd_stream_sync(void *stream);
+/* a hipStream_t for hosts without HIP headers: two batches of segments on two streams overlap one batch's
+ * PCIe copies with the other's kernels (host/encode_p.cpp --bench) */
+int x265amd_stream_create(void **stream);
+int x265amd_stream_destroy(void *stream);
 
 /* g_aucChromaScale[qp], src/table.cpp:166-171 (QP used for the chroma planes,
  * src/encode.cpp:596).  Host-side helper, no device work.  qp 0..51. */

@@ -53,9 +53,13 @@ SIGNATURES = {
     "x265amd_strerror": (C.c_char_p, [C.c_int]),
     "x265amd_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "x265amd_free": (C.c_int, [C.c_void_p]),
+    "x265amd_malloc_host": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "x265amd_free_host": (C.c_int, [C.c_void_p]),
     "x265amd_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "x265amd_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "x265amd_stream_sync": (C.c_int, [C.c_void_p]),
+    "x265amd_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "x265amd_stream_destroy": (C.c_int, [C.c_void_p]),
     "x265amd_chroma_qp": (C.c_int, [C.c_int]),
     "x265amd_sad_blocks": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -66,6 +66,17 @@ extern "C" int x265amd_free(void *d_ptr)
     X265AMD_HIP(hipFree(d_ptr));
     return X265AMD_OK;
 }
+extern "C" int x265amd_malloc_host(void **h_ptr, size_t bytes)
+{
+    if (!h_ptr) return X265AMD_ERR_ARG;
+    X265AMD_HIP(hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    return X265AMD_OK;
+}
+extern "C" int x265amd_free_host(void *h_ptr)
+{
+    X265AMD_HIP(hipHostFree(h_ptr));
+    return X265AMD_OK;
+}
 extern "C" int x265amd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream)
 {
     X265AMD_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
@@ -79,6 +90,21 @@ extern "C" int x265amd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, 
 extern "C" int x265amd_stream_sync(void *stream)
 {
     X265AMD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return X265AMD_OK;
+}
+
+extern "C" int x265amd_stream_create(void **stream)
+{
+    if (!stream) return X265AMD_ERR_ARG;
+    hipStream_t s;
+    X265AMD_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return X265AMD_OK;
+}
+extern "C" int x265amd_stream_destroy(void *stream)
+{
+    if (!stream) return X265AMD_ERR_ARG;
+    X265AMD_HIP(hipStreamDestroy((hipStream_t)stream));
     return X265AMD_OK;
 }
 
