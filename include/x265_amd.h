@@ -153,6 +153,16 @@ int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int wi
                               int64_t ref_ref_stride, x265amd_mv *d_out, void *d_workspace,
                               size_t workspace_bytes, void *stream);
 
+/* Every square PU size of every CTU in ONE exhaustive pass ("per-CTU/PU" search; SURVEY.md 8f rank 4: SAD
+ * tree 16 -> 32 -> 64): each displacement's sixteen 16x16 SADs are added up the tree and each PU keeps its own
+ * winner under its own legality.  d_out64 / d_out32 / d_out16 receive exactly what x265amd_me_fullsearch
+ * writes for ctu = 64 / 32 / 16 (same layout: [(f * nrefs + r)][block raster]); any of them may be NULL.
+ * width, height multiples of 64; the unclipped (64 + 2*range)^2 window must fit in LDS, else X265AMD_ERR_LDS. */
+int x265amd_me_fullsearch_pu(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height, int stride,
+                             int range, int nframes, int64_t cur_frame_stride, int64_t ref_frame_stride,
+                             int nrefs, int64_t ref_ref_stride, x265amd_mv *d_out64, x265amd_mv *d_out32,
+                             x265amd_mv *d_out16, void *stream);
+
 /* -------------------------------------------------------- transform/quant */
 
 /* One descriptor for the three TQ entry points.  Planes are batched over

@@ -457,3 +457,36 @@ def test_pipeline_multi_reference_negative_stride(gpu, oracle, method):
         rec = oracle.tq_inverse(lvl, seq[NR + f - 1], 32, 27, 1, mv=got[f, 0], mv_ctu=64)
         np.testing.assert_array_equal(host(pipe.level)[f], lvl)
         np.testing.assert_array_equal(host(pipe.rec)[f], rec)
+
+
+# ---------------------------------------------------------------- PU tree --
+def test_me_pu_tree_vs_oracle(gpu, oracle):
+    """x265amd_me_fullsearch_pu: all square PU sizes in one pass == the oracle's search run per size.  Small
+    picture: every CTU touches a border, so the per-PU legality (a PU may move where its CTU may not) is what
+    is tested; range larger than the picture allows included."""
+    from x265_amd import synth
+    for (W, H, R, seed) in ((128, 64, 20, 3), (192, 128, 9, 4), (64, 64, 70, 5)):
+        seq = synth.make_sequence(W, H, 2, search_range=min(R, 16), seed=seed)
+        got = gpu.me_fullsearch_pu(dev(seq[1]), dev(seq[0]), R)
+        for b in (64, 32, 16):
+            want = oracle.me_fullsearch(seq[1], seq[0], b, R, nthreads=8)
+            np.testing.assert_array_equal(gpu.mv_to_numpy(got[b])[0, 0], want, f"{W}x{H} R{R} PU {b}")
+
+
+def test_me_pu_tree_equals_per_size_kernels_batched(gpu):
+    """Frames x references batch, flat (all ties) and noise content: identical to x265amd_me_fullsearch per size."""
+    from x265_amd import synth
+    W, H, R, F = 320, 192, 24, 3
+    seq = synth.make_sequence(W, H, F + 2, search_range=R, seed=8)
+    seq[2, 64:128, 64:192] = 77                      # a flat patch: every candidate inside it ties
+    rng = np.random.default_rng(1)
+    seq[4, :, 192:] = rng.integers(0, 256, (H, W - 192), dtype=np.uint8)
+    fr = dev(seq)
+    cur = fr[2:]
+    refs = torch.stack([fr[1:-1], fr[:-2]], dim=1)    # [F][2][H][W]
+    got = gpu.me_fullsearch_pu(cur, refs, R, sizes=(32, 16, 64))
+    for b in (64, 32, 16):
+        want = gpu.me_fullsearch(cur, refs, b, R, method="brute")
+        assert torch.equal(got[b], want), b
+    only16 = gpu.me_fullsearch_pu(cur, refs, R, sizes=(16,))
+    assert torch.equal(only16[16], got[16]) and list(only16) == [16]

@@ -68,6 +68,9 @@ SIGNATURES = {
     "x265amd_me_fullsearch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
+    "x265amd_me_fullsearch_pu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
     "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -244,6 +247,28 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
         _check(_lib().x265amd_me_fullsearch(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs,
                                             ref.stride(0) if f > 1 else 0, nrefs, ref.stride(1) if nrefs > 1 else 0,
                                             out.data_ptr(), _stream()), "x265amd_me_fullsearch")
+    return out
+
+
+def me_fullsearch_pu(cur, ref, search_range=64, sizes=(64, 32, 16)):
+    """Every square PU size of every CTU in one pass (x265amd_me_fullsearch_pu).  cur / ref as for
+    me_fullsearch.  Returns {size: int32 [F][R][nblocks][2]} with exactly me_fullsearch(ctu=size)'s content."""
+    cp, f, h, w, cs, cfs = _planes(cur, torch.uint8, "cur")
+    _dev(ref, torch.uint8, "ref")
+    if ref.dim() == 2:
+        ref = ref.unsqueeze(0)
+    if ref.dim() == 3:
+        ref = ref.unsqueeze(1)
+    if ref.dim() != 4 or ref.shape[0] != f or ref.shape[2:] != (h, w) or ref.stride(3) != 1 or ref.stride(2) != cs:
+        raise ValueError("ref: need [F][R][H][W] with the row stride of cur")
+    nrefs = ref.shape[1]
+    if any(b not in (64, 32, 16) for b in sizes):
+        raise ValueError("sizes: 64, 32, 16")
+    out = {b: torch.empty((f, nrefs, max(h // b, 0) * max(w // b, 0), 2), dtype=torch.int32, device=cur.device) for b in sizes}
+    ptr = lambda b: out[b].data_ptr() if b in out else None
+    _check(_lib().x265amd_me_fullsearch_pu(cp, ref.data_ptr(), w, h, cs, search_range, f, cfs,
+                                           ref.stride(0) if f > 1 else 0, nrefs, ref.stride(1) if nrefs > 1 else 0,
+                                           ptr(64), ptr(32), ptr(16), _stream()), "x265amd_me_fullsearch_pu")
     return out
 
 
