@@ -75,3 +75,26 @@ for lo, hi in ((0, 450), (450, 500), (500, 600), (600, 768), (768, 1024), (1024,
     m = (est >= lo) & (est < hi)
     if m.any():
         print("est [%d,%d): %d CTUs, n1 mean %.0f max %d, residency mean %.0f max %d" % (lo, hi, m.sum(), n1[m].mean(), n1[m].max(), (t1 - t0)[m].mean(), (t1 - t0)[m].max()))
+
+# the CUs that finish last: what ran on them
+order = np.argsort(-spans)[:4]
+cus = sorted(set(cu.tolist()))
+for oi in order:
+    c = cus[oi]
+    m = np.nonzero(cu == c)[0]
+    base = t0[m].min()
+    big = sorted([(int(t0[i] - base), int(t1[i] - t0[i]), int(n1[i]), int(est[i]), int(s[i, 9])) for i in m if t1[i] - t0[i] > 80000])
+    print("CU %#x (XCC %d): span %d, %d CTUs; long ones (start, residency, n1, est, wg): %s" % (c, c >> 8, spans[oi], len(m), big[:12]))
+# are the persistent workgroups spread evenly?  workgroup id -> CU
+wg = s[:, 9]
+per_cu_wgs = {}
+for i in range(len(wg)):
+    per_cu_wgs.setdefault(int(cu[i]), set()).add(int(wg[i]))
+cnt = np.array([len(v) for v in per_cu_wgs.values()])
+print("distinct persistent workgroups per CU: min %d max %d; CUs with 1: %d, 2: %d, 3+: %d" % (cnt.min(), cnt.max(), (cnt == 1).sum(), (cnt == 2).sum(), (cnt >= 3).sum()))
+for x in sorted(set(xcc.tolist())):
+    ws = set()
+    for c, v in per_cu_wgs.items():
+        if c >> 8 == x:
+            ws |= v
+    print("  XCC %d: %d persistent workgroups" % (x, len(ws)))

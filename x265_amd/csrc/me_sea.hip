@@ -581,16 +581,22 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             }
         return order[(size_t)c * total + ((uint32_t)it - beg)];
     };
+    int it_now = 0;  // (thread 0) position of the current CTU in the hand-out order
     if (tid == 0) {
-        const int it = (int)atomicAdd(&ctrl[kClasses], 1u);
-        next_ctu = it < total ? (int)item_ctu(it) : -1;
+        it_now = (int)atomicAdd(&ctrl[kClasses], 1u);
+        next_ctu = it_now < total ? (int)item_ctu(it_now) : -1;
     }
     __syncthreads();
     int ctu_now = next_ctu;
   while (ctu_now >= 0) {
+    // The next CTU's index is fetched while this one is searched -- but only when this one is light.  A
+    // workgroup that reserves its next CTU while it starts on one of the two heaviest classes may reserve
+    // another of them (the queues' heads go out within microseconds of the launch) and run the two
+    // back to back: 1.0 M + 0.5 M cycles on one workgroup while the kernel's mean per CU is 1.09 M.
     int it_next = 0;
     uint32_t ctu_next_v = 0;
-    if (tid == 0) {
+    const bool reserve = tid == 0 && (uint32_t)it_now >= cls_end[1];
+    if (reserve) {
         it_next = (int)atomicAdd(&ctrl[kClasses], 1u);
         ctu_next_v = item_ctu(it_next < total ? it_next : 0);
     }
@@ -797,7 +803,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             stats[16 * ctu_id + 9] = (uint32_t)blockIdx.x;
             stats[16 * ctu_id + 7] = (__builtin_amdgcn_s_getreg(63492) & 0xffffu) | (__builtin_amdgcn_s_getreg(6164) << 16);  // HW_ID | XCC_ID
         }
+        if (!reserve) {  // a heavy CTU: ask only now that it is done
+            it_next = (int)atomicAdd(&ctrl[kClasses], 1u);
+            ctu_next_v = item_ctu(it_next < total ? it_next : 0);
+        }
         next_ctu = it_next < total ? (int)ctu_next_v : -1;
+        it_now = it_next;
     }
     __syncthreads();  // the window and part[] are free again; next_ctu is visible
     ctu_now = next_ctu;
