@@ -72,3 +72,23 @@ def test_cpp_host_closed_loop_vs_oracle(gpu, oracle, tmp_path):
         ref = np.concatenate(rec)
         np.testing.assert_array_equal(glvl[t - 1], np.concatenate(lev))
         assert hashlib.md5(grec[t - 1].tobytes()).hexdigest() == hashlib.md5(ref.tobytes()).hexdigest(), t
+
+
+@pytest.mark.gpu
+def test_cpp_host_bench_mode_streams_and_pinned_memory(gpu, tmp_path):
+    """--bench: pinned host buffers (x265amd_malloc_host), one and two streams (x265amd_stream_create) -- the
+    PCIe-inclusive loop of DESIGN.md section 5 on a small picture; both variants run and report."""
+    import json
+    from x265_amd import synth
+    W, H, T = 256, 192, 3
+    y, u, v = synth.make_sequence(W, H, T, search_range=16, seed=2, chroma=True)
+    src = tmp_path / "in.yuv"
+    np.concatenate([y.reshape(T, -1), u.reshape(T, -1), v.reshape(T, -1)], axis=1).tofile(src)
+    r = subprocess.run([EXE, "--bench", str(src), str(W), str(H), str(T), "30", "16", "2"], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert [l["streams"] for l in lines] == [1, 2]
+    for l in lines:
+        assert l["pcie_inclusive"] and l["nseg"] == 2 and l["mpixels_per_s_mean"] > 0
+        assert l["bytes_up_per_step"] == 2 * W * H * 3 // 2
