@@ -490,3 +490,20 @@ def test_me_pu_tree_equals_per_size_kernels_batched(gpu):
         assert torch.equal(got[b], want), b
     only16 = gpu.me_fullsearch_pu(cur, refs, R, sizes=(16,))
     assert torch.equal(only16[16], got[16]) and list(only16) == [16]
+
+
+@pytest.mark.parametrize("R", [0, 1, 3, 7, 13, 33])
+def test_me_odd_and_degenerate_ranges_vs_oracle(gpu, oracle, R):
+    """Search ranges that are not multiples of the 4-wide candidate groups, down to a single candidate, on a
+    picture where every CTU touches a border: elimination search, every-candidate kernel and PU tree."""
+    from x265_amd import synth
+    W, H = 192, 128
+    seq = synth.make_sequence(W, H, 2, search_range=max(R, 2), seed=50 + R)
+    want = oracle.me_fullsearch(seq[1], seq[0], 64, R, nthreads=8)
+    cur, ref = dev(seq[1]), dev(seq[0])
+    for method in ("sea", "brute"):
+        got = gpu.mv_to_numpy(gpu.me_fullsearch(cur, ref, 64, R, method=method))[0, 0]
+        np.testing.assert_array_equal(got, want, f"R {R} {method}")
+    tree = gpu.me_fullsearch_pu(cur, ref, R)
+    np.testing.assert_array_equal(gpu.mv_to_numpy(tree[64])[0, 0], want)
+    np.testing.assert_array_equal(gpu.mv_to_numpy(tree[16])[0, 0], oracle.me_fullsearch(seq[1], seq[0], 16, R, nthreads=8))
