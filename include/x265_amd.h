@@ -22,8 +22,11 @@
  *    src/params.cpp:73-74 demands of the CU size.
  *  - coefficient planes are Int16 in PICTURE GEOMETRY: level[y][x] belongs to
  *    the pixel position (x, y); the TU that owns it is (x / tu, y / tu).
- *  - a library instance is bound to one device per host thread (x265amd_init);
- *    different devices are independent (one process or thread per GPU).
+ *  - all library state is kept PER DEVICE (the role of the reference's handle X265_t,
+ *    inc/x265.h:186-212): x265amd_init(device) sets it up once per device and makes that device
+ *    current on the calling thread; every other call works on the thread's current HIP device
+ *    and returns X265AMD_ERR_NOT_INIT if x265amd_init has not run for it.  One host thread or
+ *    process per GPU, or several threads on one GPU, may call concurrently.
  */
 #ifndef X265_AMD_H
 #define X265_AMD_H
@@ -67,9 +70,10 @@ typedef struct x265amd_mv {
 
 /* ---------------------------------------------------------------- runtime */
 
-/* Select `device`, check it is gfx950, load the kernels.  Replaces nothing in
- * the reference (it has no device); closest relative is xEncInit,
- * src/encode.cpp:33-52.  Idempotent. */
+/* Select `device` (made current on the calling thread), check it is gfx950, opt every
+ * kernel in to the device's full LDS.  Replaces nothing in the reference (it has no device);
+ * closest relative is xEncInit, src/encode.cpp:33-52.  Idempotent, thread-safe; call it once
+ * per device, from each thread that will use that device (later calls only select it). */
 int x265amd_init(int device);
 int x265amd_version(void);
 const char *x265amd_strerror(int status);

@@ -1,0 +1,44 @@
+/*
+ * x265_amd_debug.h -- instrumentation hooks of libx265amd.so.  NOT part of the drop-in ABI
+ * (include/x265_amd.h): tools/, bench.py and the tests use them to time kernels, count the work of the
+ * elimination search, try kernel shapes and reach the cross-check formulation of the search.
+ *
+ * All of them are process-global and unsynchronised: one device, one thread.  A product build may drop
+ * them; nothing in include/x265_amd.h depends on them.  The reference has no counterpart (its only
+ * instrumentation is the CHECK_TV harness, src/testvec.cpp).
+ */
+#ifndef X265_AMD_DEBUG_H
+#define X265_AMD_DEBUG_H
+
+#include "x265_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* d_stats != NULL: the successive-elimination kernels run their statistics variants and write 16 u32 per
+ * (plane, CTU): [0] / [1] groups of four candidates evaluated in the first batch / the second pass, [2..6]
+ * cycle stamps of the exact kernel, [8] the work estimate, [10..13] cycle stamps of the bounds kernel.
+ * NULL switches back.  Applies to every later x265amd_me_fullsearch_sea[_static] call of the process. */
+void x265amd_debug_set_me_stats(uint32_t *d_stats);
+
+/* HIP events around the three kernels of x265amd_me_fullsearch_sea on the call's own stream; _last_ms
+ * waits for the last timed call and returns {box16_pairs, 0, sea_bounds_kernel, sea_exact_kernel} in ms. */
+int x265amd_debug_me_timing(int enable);
+int x265amd_debug_me_last_ms(float *out4);
+
+/* shape experiments of sea_exact_kernel: extra dynamic LDS per workgroup (lowers occupancy) and a forced
+ * wave count (8 or 16; 0 = the library's choice) */
+void x265amd_debug_sea_shape(int lds_pad_bytes, int waves);
+
+/* x265amd_me_fullsearch in its independent one-candidate-per-lane formulation (v_alignbyte_b32 + v_sad_u8,
+ * current block in LDS): the cross-check of the production kernels, 1.0-1.6 Gpix/s */
+int x265amd_debug_me_fullsearch_basic(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height, int stride,
+                                      int ctu, int range, int nframes, int64_t cur_frame_stride,
+                                      int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride, x265amd_mv *d_out,
+                                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X265_AMD_DEBUG_H */

@@ -19,8 +19,12 @@
  *  - the functions return what the reference's return; the status of the last
  *    call on the calling thread is x265amd_dropin_status() (0 = ok).  On error
  *    nothing is written, xSad returns 0xFFFFFFFF and xQuant returns 0.
- *  - x265amd_init() must have been called; the first drop-in call allocates a
- *    16 KB device staging block that lives until the process ends.
+ *  - x265amd_init() must have been called for the current device; the first
+ *    drop-in call on a device allocates that device's 16 KB staging block, which
+ *    lives until x265amd_dropin_teardown() (or the process) ends it.
+ *  - the drop-ins are SYNCHRONOUS helpers: they run on the null stream with
+ *    blocking copies, one call at a time per process (a mutex serialises them),
+ *    and so serialise against the caller's other default-stream work.
  *  - piTmp0 / piTmp1 (the reference's scratch) are accepted and left untouched;
  *    pDst may alias either, as at src/encode.cpp:868-872.
  *  - blocks are square, 4..32 (the only shapes the reference ever passes:
@@ -38,6 +42,8 @@ extern "C" {
 int x265amd_dropin_status(void);
 /* number of drop-in calls served by the GPU (status ok) since the library was loaded */
 uint64_t x265amd_dropin_calls(void);
+/* frees the current device's staging block (the next drop-in call allocates it again) */
+int x265amd_dropin_teardown(void);
 
 /* xSadN[0..4] = xSad4xN .. xSad64xN (typedef xSad inc/x265.h:290; src/pixel.cpp:30-101) */
 uint32_t x265amd_xSad4xN(const unsigned N, const uint8_t *pSrc, const unsigned nStrideSrc, const uint8_t *pRef, const unsigned nStrideRef);

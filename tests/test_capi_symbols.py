@@ -37,12 +37,25 @@ def test_library_exports_every_dropin_symbol():
     the reference's pixel layer (inc/x265.h:290-298)."""
     from x265_amd import api
     syms = declared_symbols("x265_amd_dropin.h")
-    assert len(syms) == 2 + 5 + 10 + 4
+    assert len(syms) == 3 + 5 + 10 + 4
     lib = C.CDLL(api.LIB_PATH)
     for name in syms:
         assert hasattr(lib, name), f"{name} declared in include/x265_amd_dropin.h but not exported"
     assert sorted(api.DROPIN_SIGNATURES) == syms
-    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["x265_amd.h", "x265_amd_dropin.h"]
+    assert sorted(os.listdir(os.path.join(ROOT, "include"))) == ["x265_amd.h", "x265_amd_debug.h", "x265_amd_dropin.h"]
+
+
+def test_every_exported_symbol_is_declared():
+    """The converse: nothing named x265amd_* leaves the library without a declaration in one of the three
+    headers -- the ABI (x265_amd.h), the per-block drop-ins (x265_amd_dropin.h) or the instrumentation hooks
+    (x265_amd_debug.h)."""
+    import subprocess
+    from x265_amd import api
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH], text=True)
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("x265amd_")})
+    declared = set(declared_symbols()) | set(declared_symbols("x265_amd_dropin.h")) | set(declared_symbols("x265_amd_debug.h"))
+    assert [s_ for s_ in exported if s_ not in declared] == []
+    assert sorted(api.DEBUG_SIGNATURES) == declared_symbols("x265_amd_debug.h")
 
 
 def test_dropins_report_errors_without_gpu():

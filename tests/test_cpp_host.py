@@ -92,3 +92,15 @@ def test_cpp_host_bench_mode_streams_and_pinned_memory(gpu, tmp_path):
     for l in lines:
         assert l["pcie_inclusive"] and l["nseg"] == 2 and l["mpixels_per_s_mean"] > 0
         assert l["bytes_up_per_step"] == 2 * W * H * 3 // 2
+
+
+@pytest.mark.gpu
+def test_two_host_threads_share_one_device(gpu):
+    """host/two_hosts.cpp: two threads, each with its own stream, encoder and geometry (8-wave and 16-wave
+    shapes of the exact kernel, different LDS sizes and workspaces), run concurrently; every picture's vectors,
+    levels and reconstruction equal the same encoder's run alone.  The per-device state of the library
+    ("per-device state") is what makes that safe."""
+    exe = os.path.join(ROOT, "x265_amd", "lib", "x265amd_two_hosts")
+    assert os.path.exists(exe), "build first: make -C host"
+    r = subprocess.run([exe, "0", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "two_hosts ok" in r.stdout, r.stderr + r.stdout

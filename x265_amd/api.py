@@ -89,9 +89,21 @@ SIGNATURES = {
 _SAD = (C.c_uint32, [C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, C.c_uint])
 _DCT = (None, [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int])
 _BLK = (None, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint])
+# include/x265_amd_debug.h: instrumentation hooks (tools/, bench.py, tests), not part of the drop-in ABI
+DEBUG_SIGNATURES = {
+    "x265amd_debug_set_me_stats": (None, [C.c_void_p]),
+    "x265amd_debug_me_timing": (C.c_int, [C.c_int]),
+    "x265amd_debug_me_last_ms": (C.c_int, [C.POINTER(C.c_float)]),
+    "x265amd_debug_sea_shape": (None, [C.c_int, C.c_int]),
+    "x265amd_debug_me_fullsearch_basic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                                     C.c_void_p]),
+}
+
 DROPIN_SIGNATURES = {
     "x265amd_dropin_status": (C.c_int, []),
     "x265amd_dropin_calls": (C.c_uint64, []),
+    "x265amd_dropin_teardown": (C.c_int, []),
     **{f"x265amd_xSad{w}xN": _SAD for w in (4, 8, 16, 32, 64)},
     **{f"x265amd_{n}": _DCT for n in ("xDST4", "xDCT4", "xDCT8", "xDCT16", "xDCT32",
                                        "xInvDST4", "xInvDCT4", "xInvDCT8", "xInvDCT16", "xInvDCT32")},
@@ -110,7 +122,7 @@ def _lib():
                 f"{LIB_PATH} is missing: build it with `make -C x265_amd/csrc` "
                 "(or __graft_entry__.build()).  There is no CPU fallback.")
         lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in {**SIGNATURES, **DROPIN_SIGNATURES}.items():
+        for name, (res, args) in {**SIGNATURES, **DROPIN_SIGNATURES, **DEBUG_SIGNATURES}.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
@@ -225,7 +237,6 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
         raise ValueError("method")
     if method == "basic":  # the one-candidate-per-lane cross-check kernel (debug entry point, not in the header)
         fn = _lib().x265amd_debug_me_fullsearch_basic
-        fn.restype, fn.argtypes = SIGNATURES["x265amd_me_fullsearch"]
         _check(fn(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs, ref.stride(0) if f > 1 else 0, nrefs,
                   ref.stride(1) if nrefs > 1 else 0, out.data_ptr(), _stream()), "x265amd_debug_me_fullsearch_basic")
         return out

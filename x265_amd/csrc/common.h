@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/x265_amd.h"
 
 namespace x265amd {
@@ -15,10 +17,46 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? X265AMD_OK : X265
         if (e_ != hipSuccess) return ::x265amd::hip_status(e_); \
     } while (0)
 
-// set by x265amd_init(); entry points refuse to launch before it
-bool initialised();
+// ---- per-device state ----------------------------------------------------------------------------
+// The reference keeps all encoder state in its handle (X265_t, inc/x265.h:186-212).  Here the handle is
+// the HIP device: everything the library remembers is kept PER DEVICE, indexed by the device that is
+// current on the calling thread, and filled in by x265amd_init(device).  One host thread (or process)
+// per GPU, or several threads on one GPU, can therefore use the library side by side; the mutable parts
+// (the occupancy cache, the drop-in staging block) are guarded by state_mutex().
+constexpr int kMaxDevices = 64;
+constexpr int kOccSlots = 8;
+
+struct OccEntry {  // occupancy of one kernel variant at one dynamic-LDS size
+    const void *fn;
+    size_t lds;
+    int per_cu;
+};
+
+struct DeviceState {
+    bool init = false;
+    int lds_limit = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950)
+    int cu_count = 256;
+    void *dropin_stage = nullptr;    // dropin.hip's staging block on this device
+    OccEntry occ[kOccSlots] = {};
+    int nocc = 0;
+};
+
+// state of the device that is current on this thread; nullptr until x265amd_init() has run for it
+DeviceState *device_state();
+std::mutex &state_mutex();
+
+inline bool initialised() { return device_state() != nullptr; }
 int lds_limit_bytes();
 int cu_count();
+
+// per-source-file set-up that x265amd_init(device) runs once per device, with that device current:
+// the opt-in of every kernel to the device's full LDS (so no launch path touches function attributes)
+int me_kernels_device_setup(DeviceState &ds);
+int me_tree_device_setup(DeviceState &ds);
+int me_sea_device_setup(DeviceState &ds);
+
+// dynamic-LDS opt-in of one kernel: the device limit minus the kernel's own static LDS
+int allow_full_lds(const void *fn, const DeviceState &ds);
 
 inline int ilog2(int n)
 {

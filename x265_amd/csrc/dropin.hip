@@ -60,18 +60,28 @@ struct Stage {  // device-side staging of one block
     uint8_t mode[4];
 };
 
-std::mutex g_mu;
-Stage *g_stage = nullptr;
+std::mutex g_mu;                   // one drop-in call at a time (they are synchronous, null-stream helpers)
+thread_local Stage *g_stage = nullptr;  // the staging block of the device current on this thread (set by stage_ready)
 thread_local int t_status = X265AMD_OK;
 std::atomic<uint64_t> g_calls{0};  // calls that reached the GPU and came back ok
 
+// one staging block per device, allocated at the first drop-in call on that device, freed by
+// x265amd_dropin_teardown().  Callers hold g_mu.
 int stage_ready()
 {
-    if (!initialised()) return X265AMD_ERR_NOT_INIT;
-    if (!g_stage) {
-        X265AMD_HIP(hipMalloc((void **)&g_stage, sizeof(Stage)));
-        X265AMD_HIP(hipMemset(g_stage, 0, sizeof(Stage)));
+    DeviceState *ds = device_state();
+    if (!ds) return X265AMD_ERR_NOT_INIT;
+    if (!ds->dropin_stage) {
+        void *p = nullptr;
+        X265AMD_HIP(hipMalloc(&p, sizeof(Stage)));
+        const hipError_t e = hipMemset(p, 0, sizeof(Stage));
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            return hip_status(e);
+        }
+        ds->dropin_stage = p;
     }
+    g_stage = (Stage *)ds->dropin_stage;
     return X265AMD_OK;
 }
 
@@ -198,6 +208,19 @@ int dequant(int16_t *dst, const int16_t *src, unsigned stride, unsigned qp, int 
 using namespace x265amd;
 
 extern "C" int x265amd_dropin_status(void) { return t_status; }
+extern "C" int x265amd_dropin_teardown(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    DeviceState *ds = device_state();
+    if (!ds) return X265AMD_ERR_NOT_INIT;
+    if (ds->dropin_stage) {
+        X265AMD_HIP(hipDeviceSynchronize());
+        X265AMD_HIP(hipFree(ds->dropin_stage));
+        ds->dropin_stage = nullptr;
+    }
+    g_stage = nullptr;
+    return X265AMD_OK;
+}
 extern "C" uint64_t x265amd_dropin_calls(void) { return g_calls.load(); }
 
 static int served(int status)

@@ -270,6 +270,18 @@ __global__ __launch_bounds__(256, 2) void me_fullsearch_qsad(const uint8_t *__re
     }
 }
 
+// x265amd_init, once per device: every search kernel may use the device's whole LDS from then on
+int me_kernels_device_setup(DeviceState &ds)
+{
+    const void *fns[] = {(const void *)me_fullsearch_qsad<64>, (const void *)me_fullsearch_qsad<32>,
+                         (const void *)me_fullsearch_qsad<16>, (const void *)me_fullsearch_basic};
+    for (const void *fn : fns) {
+        const int st = allow_full_lds(fn, ds);
+        if (st != X265AMD_OK) return st;
+    }
+    return X265AMD_OK;
+}
+
 }  // namespace x265amd
 
 using namespace x265amd;
@@ -330,9 +342,6 @@ extern "C" int x265amd_me_fullsearch(const uint8_t *d_cur, const uint8_t *d_ref,
         const size_t lds = (size_t)max_rows * max_pitch * 4;
         if (lds + 64 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;
         const dim3 grid(g.ctus_x, g.ctus_y, nframes * nrefs);
-        const void *fn = ctu == 64 ? (const void *)me_fullsearch_qsad<64>
-                                   : ctu == 32 ? (const void *)me_fullsearch_qsad<32> : (const void *)me_fullsearch_qsad<16>;
-        X265AMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         if (ctu == 64)
             hipLaunchKernelGGL(me_fullsearch_qsad<64>, grid, dim3(256), lds, (hipStream_t)stream, d_cur, d_ref, d_out, g);
         else if (ctu == 32)
@@ -378,8 +387,6 @@ extern "C" int x265amd_debug_me_fullsearch_basic(const uint8_t *d_cur, const uin
     p.win_dw = (ctu + 2 * range + 3) / 4 + 2;  // + dword-alignment slack + the hi dword of the last alignbyte
     const size_t lds = ((size_t)p.win_rows * p.win_dw + (size_t)ctu * ctu / 4) * 4;
     if (lds + 64 > (size_t)lds_limit_bytes()) return X265AMD_ERR_LDS;
-    X265AMD_HIP(hipFuncSetAttribute((const void *)me_fullsearch_basic, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
     hipLaunchKernelGGL(me_fullsearch_basic, dim3(p.ctus_x, p.ctus_y, nframes * nrefs), dim3(256), lds,
                        (hipStream_t)stream, p);
     return hip_status(hipGetLastError());

@@ -815,16 +815,30 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
   }
 }
 
+
+int me_sea_device_setup(DeviceState &ds)
+{
+    const void *fns[] = {(const void *)sea_bounds_kernel, (const void *)sea_exact_kernel<false, 8>,
+                         (const void *)sea_exact_kernel<true, 8>, (const void *)sea_exact_kernel<false, 16>,
+                         (const void *)sea_exact_kernel<true, 16>};
+    for (const void *fn : fns) {
+        const int st = allow_full_lds(fn, ds);
+        if (st != X265AMD_OK) return st;
+    }
+    return X265AMD_OK;
+}
+
 }  // namespace x265amd
 
 using namespace x265amd;
 
+// ---- debugging aids (include/x265_amd_debug.h; process-global, one device, one thread) ----
 static uint32_t *g_me_stats = nullptr;
-// debugging aid (not part of the ABI): 16 u32 per CTU; [0] / [1] = groups evaluated in pass 0 / 1
+// 16 u32 per CTU; [0] / [1] = groups evaluated in pass 0 / 1; switches both kernels to their stats variants
 extern "C" void x265amd_debug_set_me_stats(uint32_t *d_stats) { g_me_stats = d_stats; }
 
-// debugging aid (not part of the ABI): per-kernel HIP-event timing of the last _sea call on its own stream.
-// bench.py uses it so that the roofline line can name each kernel's duration without a profiler attached.
+// per-kernel HIP-event timing of the last _sea call on its own stream.  bench.py uses it so that the
+// roofline line can name each kernel's duration without a profiler attached.
 static bool g_me_timing = false;
 static hipEvent_t g_me_ev[5];
 extern "C" int x265amd_debug_me_timing(int enable)
@@ -841,6 +855,14 @@ extern "C" int x265amd_debug_me_last_ms(float *out4)
     X265AMD_HIP(hipEventSynchronize(g_me_ev[4]));
     for (int i = 0; i < 4; i++) X265AMD_HIP(hipEventElapsedTime(&out4[i], g_me_ev[i], g_me_ev[i + 1]));
     return X265AMD_OK;
+}
+// shape experiments of the exact kernel (A/B runs of tools/): extra dynamic LDS per workgroup, forced wave count
+// (0 = the library's own choice)
+static int g_sea_lds_pad = 0, g_sea_waves = 0;
+extern "C" void x265amd_debug_sea_shape(int lds_pad_bytes, int waves)
+{
+    g_sea_lds_pad = lds_pad_bytes > 0 ? lds_pad_bytes : 0;
+    g_sea_waves = waves;
 }
 
 // largest per-CTU geometry of a picture: rows / pitch of the window, groups per row, rows of candidates
@@ -876,48 +898,56 @@ extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, i
            + align256(sizeof(uint16_t) * per_ctu * kMaxWgLists);           // second-pass schedules of 16-wave workgroups
 }
 
-// as many workgroups as the chip holds at once (LDS- and register-bound), each looping over CTUs
-template <int WAVES>
-static int launch_exact(size_t lds, hipStream_t st, const uint8_t *d_cur, const uint8_t *d_ref, const uint16_t *gl,
-                        const uint16_t *list0, uint16_t *wg_list, const SeaHdr *hdr, const uint32_t *order, uint32_t *ctrl,
-                        int total, x265amd_mv *d_out, const MeGeom &g, int gl_pitch, int win_dwords)
+// workgroups of one exact-kernel variant that a CU holds at this dynamic-LDS size: asked once per device,
+// variant and size (a host-side computation, but not a free one), then served from the device's cache
+static int exact_per_cu(DeviceState &ds, const void *fn, int threads, size_t lds, int &per_cu)
 {
-    const bool st_variant = g_me_stats != nullptr;
-    const void *fn = st_variant ? (const void *)sea_exact_kernel<true, WAVES> : (const void *)sea_exact_kernel<false, WAVES>;
-    // the LDS opt-in and the occupancy query are host round trips: once per (variant, LDS size)
-    // and device (a cache of one entry: a process drives one GPU)
-    static size_t seen_lds[2] = {~(size_t)0, ~(size_t)0};
-    static int seen_per_cu[2] = {0, 0}, seen_dev[2] = {-1, -1};
-    int dev = -1;
-    X265AMD_HIP(hipGetDevice(&dev));
-    if (seen_lds[st_variant] != lds || seen_dev[st_variant] != dev) {
-        X265AMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        int q = 0;
-        X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, WAVES * 64, lds));
-        seen_per_cu[st_variant] = q;
-        seen_lds[st_variant] = lds;
-        seen_dev[st_variant] = dev;
-    }
-    const int per_cu = seen_per_cu[st_variant];
-    if (per_cu < 1) return X265AMD_ERR_LDS;
-    int resident = per_cu * cu_count();
-    if (WAVES == 16 && resident > kMaxWgLists) resident = kMaxWgLists;  // schedule slices in the workspace
-    const dim3 grid((unsigned)(total < resident ? total : resident));
-    if (g_me_stats)
-        hipLaunchKernelGGL((sea_exact_kernel<true, WAVES>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
-                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
-    else
-        hipLaunchKernelGGL((sea_exact_kernel<false, WAVES>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
-                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, g_me_stats);
+    std::lock_guard<std::mutex> lk(state_mutex());
+    for (int i = 0; i < ds.nocc; i++)
+        if (ds.occ[i].fn == fn && ds.occ[i].lds == lds) {
+            per_cu = ds.occ[i].per_cu;
+            return X265AMD_OK;
+        }
+    int q = 0;
+    X265AMD_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, fn, threads, lds));
+    OccEntry &e = ds.occ[ds.nocc < kOccSlots ? ds.nocc++ : (kOccSlots - 1)];  // full: the last slot is recycled
+    e.fn = fn;
+    e.lds = lds;
+    e.per_cu = q;
+    per_cu = q;
     return X265AMD_OK;
 }
 
-extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
-                                         int stride, int ctu, int range, int nframes, int64_t cur_frame_stride,
-                                         int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride,
-                                         x265amd_mv *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
+// as many workgroups as the chip holds at once (LDS- and register-bound), each looping over CTUs
+template <int WAVES>
+static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8_t *d_cur, const uint8_t *d_ref,
+                        const uint16_t *gl, const uint16_t *list0, uint16_t *wg_list, const SeaHdr *hdr,
+                        const uint32_t *order, uint32_t *ctrl, int total, x265amd_mv *d_out, const MeGeom &g, int gl_pitch,
+                        int win_dwords)
 {
-    if (!initialised()) return X265AMD_ERR_NOT_INIT;
+    uint32_t *const stats = g_me_stats;  // read once: the variant and its argument must agree
+    const void *fn = stats ? (const void *)sea_exact_kernel<true, WAVES> : (const void *)sea_exact_kernel<false, WAVES>;
+    int per_cu = 0;
+    const int ost = exact_per_cu(ds, fn, WAVES * 64, lds, per_cu);
+    if (ost != X265AMD_OK) return ost;
+    if (per_cu < 1) return X265AMD_ERR_LDS;
+    int resident = per_cu * ds.cu_count;
+    if (WAVES == 16 && resident > kMaxWgLists) resident = kMaxWgLists;  // schedule slices in the workspace
+    const dim3 grid((unsigned)(total < resident ? total : resident));
+    if (stats)
+        hipLaunchKernelGGL((sea_exact_kernel<true, WAVES>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
+                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, stats);
+    else
+        hipLaunchKernelGGL((sea_exact_kernel<false, WAVES>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
+                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, stats);
+    return X265AMD_OK;
+}
+
+// the search on the caller's workspace: three launches, nothing allocated
+static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_ref, int width, int height, int stride, int ctu,
+                      int range, int nframes, int64_t cur_frame_stride, int64_t ref_frame_stride, int nrefs,
+                      int64_t ref_ref_stride, x265amd_mv *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
     if (!d_cur || !d_ref || !d_out || !d_workspace) return X265AMD_ERR_ARG;
     if (ctu != 64) return X265AMD_ERR_ARG;
     if (width <= 0 || height <= 0 || width % 64 || height % 64 || stride < width) return X265AMD_ERR_ARG;
@@ -939,12 +969,11 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     const size_t list_bytes = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
     // 8-wave workgroups (window + schedule in LDS, 16 KB of partial sums) when two of them fit a CU;
     // otherwise ONE 16-wave workgroup per CU (window only + 32 KB of partial sums, schedule in the workspace)
-    size_t lds8 = (size_t)win_dwords * 4 + list_bytes;
-    if (const char *pad = getenv("X265AMD_SEA_LDS_PAD")) lds8 += (size_t)atoi(pad);  // occupancy experiments only
+    const size_t lds8 = (size_t)win_dwords * 4 + list_bytes + (size_t)g_sea_lds_pad;
     const size_t lds16 = (size_t)win_dwords * 4;
-    const size_t lds_cap = (size_t)lds_limit_bytes();
+    const size_t lds_cap = (size_t)ds.lds_limit;
     bool waves16 = 2 * (lds8 + 17408) > lds_cap;
-    if (const char *e = getenv("X265AMD_SEA_WAVES")) waves16 = atoi(e) == 16;  // A/B experiments only
+    if (g_sea_waves) waves16 = g_sea_waves == 16;
     if (waves16 && lds16 + 33792 > lds_cap) waves16 = false;
     if (!waves16 && lds8 + 17408 > lds_cap) return X265AMD_ERR_LDS;  // + the kernel's static LDS
     const size_t lds_bounds = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
@@ -989,12 +1018,23 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;
     if (waves16)
-        status = launch_exact<16>(lds16, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch,
+        status = launch_exact<16>(ds, lds16, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch,
                                   win_dwords);
     else
-        status = launch_exact<8>(lds8, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch,
+        status = launch_exact<8>(ds, lds8, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch,
                                  win_dwords);
     if (status != X265AMD_OK) return status;
     if (timing) (void)hipEventRecord(g_me_ev[4], st);
     return hip_status(hipGetLastError());
+}
+
+extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
+                                         int stride, int ctu, int range, int nframes, int64_t cur_frame_stride,
+                                         int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride,
+                                         x265amd_mv *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
+{
+    DeviceState *ds = device_state();
+    if (!ds) return X265AMD_ERR_NOT_INIT;
+    return sea_search(*ds, d_cur, d_ref, width, height, stride, ctu, range, nframes, cur_frame_stride, ref_frame_stride,
+                      nrefs, ref_ref_stride, d_out, d_workspace, workspace_bytes, stream);
 }

@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256, 2) void me_tree_kernel(const uint8_t *__restri
     }
 }
 
+int me_tree_device_setup(DeviceState &ds) { return allow_full_lds((const void *)me_tree_kernel, ds); }
+
 }  // namespace x265amd
 
 using namespace x265amd;
@@ -185,11 +187,6 @@ extern "C" int x265amd_me_fullsearch_pu(const uint8_t *d_cur, const uint8_t *d_r
     g.cur_fs = cur_frame_stride;
     g.ref_fs = ref_frame_stride;
     g.ref_rs = ref_ref_stride;
-    static size_t seen_lds = 0;
-    if (lds > seen_lds) {
-        X265AMD_HIP(hipFuncSetAttribute((const void *)me_tree_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        seen_lds = lds;
-    }
     TreeOut out{d_out64, d_out32, d_out16};
     hipLaunchKernelGGL(me_tree_kernel, dim3(g.ctus_x, g.ctus_y, (unsigned)(nframes * nrefs)), dim3(256), lds, (hipStream_t)stream,
                        d_cur, d_ref, out, g, pitch);

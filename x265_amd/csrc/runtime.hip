@@ -1,20 +1,42 @@
 // runtime.hip -- device selection, error strings, memory helpers of the C-ABI
 #include <string.h>
 
-#include <mutex>
-
 #include "common.h"
 
 namespace x265amd {
 
 static std::mutex g_mu;
-static bool g_init = false;
-static int g_lds_limit = 64 * 1024;
-static int g_cu_count = 256;
+static DeviceState g_dev[kMaxDevices];
 
-bool initialised() { return g_init; }
-int lds_limit_bytes() { return g_lds_limit; }
-int cu_count() { return g_cu_count; }
+std::mutex &state_mutex() { return g_mu; }
+
+DeviceState *device_state()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    DeviceState *ds = &g_dev[dev];
+    return ds->init ? ds : nullptr;  // `init` is set last, under the lock, and never cleared
+}
+int lds_limit_bytes()
+{
+    const DeviceState *ds = device_state();
+    return ds ? ds->lds_limit : 64 * 1024;
+}
+int cu_count()
+{
+    const DeviceState *ds = device_state();
+    return ds ? ds->cu_count : 256;
+}
+
+int allow_full_lds(const void *fn, const DeviceState &ds)
+{
+    hipFuncAttributes fa;
+    X265AMD_HIP(hipFuncGetAttributes(&fa, fn));
+    const int dyn = ds.lds_limit - (int)fa.sharedSizeBytes;
+    if (dyn <= 0) return X265AMD_ERR_LDS;
+    X265AMD_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, dyn));
+    return X265AMD_OK;
+}
 
 }  // namespace x265amd
 
@@ -27,16 +49,23 @@ extern "C" int x265amd_init(int device)
     std::lock_guard<std::mutex> lk(g_mu);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return X265AMD_ERR_NO_DEVICE;
-    if (device < 0 || device >= n) return X265AMD_ERR_NO_DEVICE;
+    if (device < 0 || device >= n || device >= kMaxDevices) return X265AMD_ERR_NO_DEVICE;
     X265AMD_HIP(hipSetDevice(device));
+    DeviceState &ds = g_dev[device];
+    if (ds.init) return X265AMD_OK;  // idempotent; the device is current on this thread now
     hipDeviceProp_t prop;
     X265AMD_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return X265AMD_ERR_ARCH;  // kernels are built for gfx950 only
     int lds = 0;
     if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
-        g_lds_limit = lds;
-    if (prop.multiProcessorCount > 0) g_cu_count = prop.multiProcessorCount;
-    g_init = true;
+        ds.lds_limit = lds;
+    if (prop.multiProcessorCount > 0) ds.cu_count = prop.multiProcessorCount;
+    // once per device, with that device current: LDS opt-ins and the scratch array's address
+    int st = me_kernels_device_setup(ds);
+    if (st == X265AMD_OK) st = me_tree_device_setup(ds);
+    if (st == X265AMD_OK) st = me_sea_device_setup(ds);
+    if (st != X265AMD_OK) return st;
+    ds.init = true;
     return X265AMD_OK;
 }
 
@@ -47,7 +76,7 @@ extern "C" const char *x265amd_strerror(int status)
     case X265AMD_ERR_ARG: return "invalid argument (geometry, size, alignment or null pointer)";
     case X265AMD_ERR_NO_DEVICE: return "no such HIP device";
     case X265AMD_ERR_ARCH: return "device is not gfx950 (MI355X); this library has no other code path";
-    case X265AMD_ERR_NOT_INIT: return "x265amd_init() has not been called";
+    case X265AMD_ERR_NOT_INIT: return "x265amd_init() has not been called for the current device";
     case X265AMD_ERR_LDS: return "search window does not fit in LDS";
     default: break;
     }
