@@ -58,6 +58,7 @@ enum {
     X265AMD_ERR_ARCH = -3,      /* device is not gfx950 */
     X265AMD_ERR_NOT_INIT = -4,  /* x265amd_init() not called */
     X265AMD_ERR_LDS = -5,       /* search window does not fit the 160 KiB LDS */
+    X265AMD_ERR_WORKSPACE = -6, /* x265amd_me_fullsearch_sea_static: the job needs more than the static scratch */
     X265AMD_ERR_HIP = -1000     /* -1000 - hipError_t */
 };
 
@@ -156,6 +157,21 @@ int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int wi
                               int64_t cur_frame_stride, int64_t ref_frame_stride, int nrefs,
                               int64_t ref_ref_stride, x265amd_mv *d_out, void *d_workspace,
                               size_t workspace_bytes, void *stream);
+
+/* x265amd_me_fullsearch_sea for callers that cannot allocate or bring a workspace (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.
+ * Same kernels, same arguments minus the workspace: the scratch lives in a static device array of
+ * X265AMD_ME_STATIC_WORKSPACE_BYTES (40 MiB per GPU, held from library load to process end) whose address is
+ * taken once per device in x265amd_init.  The call allocates nothing.  Jobs whose
+ * x265amd_me_workspace_bytes() exceeds the array (e.g. more than two 1080p planes at range 64) are refused with
+ * X265AMD_ERR_WORKSPACE -- use x265amd_me_fullsearch_sea for those.  Every call on a GPU shares that GPU's
+ * array: calls that overlap on one GPU (two streams, two threads) race; serialise them. */
+#define X265AMD_ME_STATIC_WORKSPACE_BYTES (40u << 20)
+size_t x265amd_me_static_workspace_bytes(void);
+int x265amd_me_fullsearch_sea_static(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
+                                     int stride, int ctu, int range, int nframes,
+                                     int64_t cur_frame_stride, int64_t ref_frame_stride, int nrefs,
+                                     int64_t ref_ref_stride, x265amd_mv *d_out, void *stream);
 
 /* Every square PU size of every CTU in ONE exhaustive pass ("per-CTU/PU" search; SURVEY.md 8f rank 4: SAD
  * tree 16 -> 32 -> 64): each displacement's sixteen 16x16 SADs are added up the tree and each PU keeps its own

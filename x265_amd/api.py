@@ -75,6 +75,10 @@ SIGNATURES = {
     "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "x265amd_me_static_workspace_bytes": (C.c_size_t, []),
+    "x265amd_me_fullsearch_sea_static": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                    C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
+                                                    C.c_void_p]),
     "x265amd_tq_forward": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
     "x265amd_tq_inverse": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
     "x265amd_idct_add": (C.c_int, [C.POINTER(TqDesc), C.c_void_p]),
@@ -212,6 +216,10 @@ def me_workspace_bytes(width, height, search_range, nframes, nrefs):
     return int(_lib().x265amd_me_workspace_bytes(width, height, search_range, nframes, nrefs))
 
 
+def me_static_workspace_bytes():
+    return int(_lib().x265amd_me_static_workspace_bytes())
+
+
 def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", workspace=None):
     """cur: uint8 [F][H][W]; ref: uint8 [F][H][W] (one reference per frame) or
     [F][R][H][W] (R references per frame).  Returns int32 [F][R][nctu][2] viewed as
@@ -220,6 +228,8 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
     method: "brute" = x265amd_me_fullsearch (every candidate's SAD), "sea" =
     x265amd_me_fullsearch_sea (exact successive elimination, same result; CTU 64 only;
     `workspace` = uint8 CUDA tensor of me_workspace_bytes() or None to allocate one),
+    "sea_static" = x265amd_me_fullsearch_sea_static (the same search on the library's static scratch: the
+    call allocates nothing, `out` must be given; jobs beyond me_static_workspace_bytes() are refused),
     "auto" = "sea" where it applies; "basic" = the independent one-candidate-per-lane kernel (tests)."""
     cp, f, h, w, cs, cfs = _planes(cur, torch.uint8, "cur")
     _dev(ref, torch.uint8, "ref")
@@ -233,8 +243,14 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
     nctu = (h // ctu) * (w // ctu) if ctu > 0 else 0
     if out is None:
         out = torch.empty((f, nrefs, max(nctu, 0), 2), dtype=torch.int32, device=cur.device)
-    if method not in ("auto", "brute", "sea", "basic"):
+    if method not in ("auto", "brute", "sea", "sea_static", "basic"):
         raise ValueError("method")
+    if method == "sea_static":
+        _check(_lib().x265amd_me_fullsearch_sea_static(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs,
+                                                       ref.stride(0) if f > 1 else 0, nrefs,
+                                                       ref.stride(1) if nrefs > 1 else 0, out.data_ptr(), _stream()),
+               "x265amd_me_fullsearch_sea_static")
+        return out
     if method == "basic":  # the one-candidate-per-lane cross-check kernel (debug entry point, not in the header)
         fn = _lib().x265amd_debug_me_fullsearch_basic
         _check(fn(cp, ref.data_ptr(), w, h, cs, ctu, search_range, f, cfs, ref.stride(0) if f > 1 else 0, nrefs,

@@ -36,6 +36,8 @@ struct DeviceState {
     bool init = false;
     int lds_limit = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950)
     int cu_count = 256;
+    void *sea_scratch = nullptr;     // device address of me_sea.hip's static scratch array ON THIS DEVICE
+    size_t sea_scratch_bytes = 0;
     void *dropin_stage = nullptr;    // dropin.hip's staging block on this device
     OccEntry occ[kOccSlots] = {};
     int nocc = 0;
@@ -51,6 +53,7 @@ int cu_count();
 
 // per-source-file set-up that x265amd_init(device) runs once per device, with that device current:
 // the opt-in of every kernel to the device's full LDS (so no launch path touches function attributes)
+// and, in me_sea.hip, the address of the static scratch array on that device
 int me_kernels_device_setup(DeviceState &ds);
 int me_tree_device_setup(DeviceState &ds);
 int me_sea_device_setup(DeviceState &ds);

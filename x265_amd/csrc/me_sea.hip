@@ -815,6 +815,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Static scratch for x265amd_me_fullsearch_sea_static: the workspace of the search (pair plane, bounds,
+// first-batch lists, headers, queues, second-pass schedules) for callers that cannot allocate.  Every GPU
+// the library runs on holds its own copy of this array, at its own address, until the process ends;
+// host code never uses the array's name as an address -- only the pointer hipGetSymbolAddress returned
+// for that device (DeviceState::sea_scratch).
+// ---------------------------------------------------------------------------------------------
+constexpr size_t kSeaStaticBytes = (size_t)X265AMD_ME_STATIC_WORKSPACE_BYTES;
+static __device__ __align__(256) unsigned char sea_scratch[kSeaStaticBytes];
 
 int me_sea_device_setup(DeviceState &ds)
 {
@@ -825,6 +834,11 @@ int me_sea_device_setup(DeviceState &ds)
         const int st = allow_full_lds(fn, ds);
         if (st != X265AMD_OK) return st;
     }
+    void *p = nullptr;
+    X265AMD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(sea_scratch)));  // this device's copy of the array
+    if (!p || ((uintptr_t)p & 255)) return X265AMD_ERR_HIP - (int)hipErrorInvalidSymbol;
+    ds.sea_scratch = p;
+    ds.sea_scratch_bytes = kSeaStaticBytes;
     return X265AMD_OK;
 }
 
@@ -943,7 +957,8 @@ static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8
     return X265AMD_OK;
 }
 
-// the search on the caller's workspace: three launches, nothing allocated
+// the search on a workspace that the caller brought (x265amd_me_fullsearch_sea) or that the library
+// holds per device (x265amd_me_fullsearch_sea_static): three launches, nothing allocated
 static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_ref, int width, int height, int stride, int ctu,
                       int range, int nframes, int64_t cur_frame_stride, int64_t ref_frame_stride, int nrefs,
                       int64_t ref_ref_stride, x265amd_mv *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
@@ -1037,4 +1052,27 @@ extern "C" int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_
     if (!ds) return X265AMD_ERR_NOT_INIT;
     return sea_search(*ds, d_cur, d_ref, width, height, stride, ctu, range, nframes, cur_frame_stride, ref_frame_stride,
                       nrefs, ref_ref_stride, d_out, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t x265amd_me_static_workspace_bytes(void) { return kSeaStaticBytes; }
+
+// The same three kernels on the device's static scratch array: no hipMalloc / hipFree / allocating routine on
+// this path (the LDS opt-ins and the array's address were taken in x265amd_init; the occupancy query is host
+// arithmetic).  The kernels zero their own queue counters, and every other part of the scratch is written
+// before it is read within a call, so nothing of the previous call's contents can leak into this one.
+extern "C" int x265amd_me_fullsearch_sea_static(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
+                                                int stride, int ctu, int range, int nframes, int64_t cur_frame_stride,
+                                                int64_t ref_frame_stride, int nrefs, int64_t ref_ref_stride,
+                                                x265amd_mv *d_out, void *stream)
+{
+    DeviceState *ds = device_state();
+    if (!ds) return X265AMD_ERR_NOT_INIT;
+    if (!ds->sea_scratch) return X265AMD_ERR_NOT_INIT;
+    if (nframes > 0 && nrefs > 0) {
+        const size_t need = x265amd_me_workspace_bytes(width, height, range, nframes, nrefs);
+        if (need == 0) return X265AMD_ERR_ARG;
+        if (need > ds->sea_scratch_bytes) return X265AMD_ERR_WORKSPACE;  // beyond the static maximum: use _sea
+    }
+    return sea_search(*ds, d_cur, d_ref, width, height, stride, ctu, range, nframes, cur_frame_stride, ref_frame_stride,
+                      nrefs, ref_ref_stride, d_out, ds->sea_scratch, ds->sea_scratch_bytes, stream);
 }

@@ -78,6 +78,7 @@ extern "C" const char *x265amd_strerror(int status)
     case X265AMD_ERR_ARCH: return "device is not gfx950 (MI355X); this library has no other code path";
     case X265AMD_ERR_NOT_INIT: return "x265amd_init() has not been called for the current device";
     case X265AMD_ERR_LDS: return "search window does not fit in LDS";
+    case X265AMD_ERR_WORKSPACE: return "job exceeds the static scratch of x265amd_me_fullsearch_sea_static; use x265amd_me_fullsearch_sea with a workspace";
     default: break;
     }
     if (status <= X265AMD_ERR_HIP) return hipGetErrorString((hipError_t)(X265AMD_ERR_HIP - status));
