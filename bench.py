@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- ME+TQ throughput of the MI355X hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p|4k|8k4ref|tq1080p]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p|4k|8k4ref|tq1080p|gop1080p]
 
 One STEP = one pass of the hot path over one batch of synthetic frames that is
 already resident in HBM: exhaustive +-R integer-pel search for every 64x64 CTU
-of every frame (x265amd_me_fullsearch), then residual -> DCT -> quant -> dequant
+of every frame (x265amd_me_fullsearch_sea), then residual -> DCT -> quant -> dequant
 -> IDCT -> reconstruction with the motion-compensated prediction
 (x265amd_tq_roundtrip).  Default workload = BASELINE.json configs[1]:
 1920x1080 (padded to 1088 rows), CTU 64, R = 64, 16 frames per step, 1 reference.
 
-N > 1: one process per GPU (torchrun); every rank runs the same-sized batch of its
-own frames (weak scaling, no data-path collective -- SURVEY.md section 8e);
-torch.distributed is used for the barrier and the max-over-ranks time only.
+N > 1: one process per GPU.  Either the driver starts them (torchrun: RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or, when WORLD_SIZE is unset, this script starts N children of itself BEFORE anything touches
+the GPU and rank 0's line is the output.  ONE synthetic sequence of N x frames-per-step frames is sharded
+with x265_amd.shard_frames: rank r searches and transforms its own contiguous run of frames (weak scaling:
+the per-GPU batch is fixed; no data-path collective -- SURVEY.md section 8e).  torch.distributed provides the
+barrier, the max-over-ranks time and the gather of every rank's result digest and sample-parity flag to rank 0.
+With fewer GPUs than ranks (a rehearsal on a 1-GPU box) the ranks share devices and the group is gloo.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (the
 search) from HIP-event timing on the launch stream inside the timed region;
@@ -20,8 +24,11 @@ search) from HIP-event timing on the launch stream inside the timed region;
 bounded sample of the same workload on this box's host cores.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,8 +41,10 @@ sys.path.insert(0, ROOT)
 import x265_amd  # noqa: E402
 from x265_amd import synth  # noqa: E402
 from x265_amd.pipeline import MeTqPipeline  # noqa: E402
+from x265_amd.sharding import shard_frames  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E
+QSAD_PEAK_TPX = 152.0       # tools/ubench_valu: v_qsad_pk_u16_u8 issue rate on this chip (profiles/ubench_r1.txt)
 
 WORKLOADS = {
     # name: (nominal W, nominal H, CTU, R, nrefs, frames per step, TU, QP)
@@ -47,6 +56,9 @@ WORKLOADS = {
 }
 
 
+# ------------------------------------------------------------------------------------------------
+# launching
+# ------------------------------------------------------------------------------------------------
 def dist_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -54,10 +66,110 @@ def dist_env():
     return world, rank, local
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` outside torchrun: N children of this script, one per GPU.  Runs before this
+    process has made any GPU call (torch.cuda.device_count() makes none on this image) and starts nothing
+    after one; the children are fresh interpreters.  Rank 0 inherits stdout, so its JSON line is the output."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ndev = torch.cuda.device_count()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        if ndev < n:
+            env.setdefault("X265AMD_DIST_BACKEND", "gloo")   # rehearsal: ranks share devices, no RCCL ring possible
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+class Group:
+    """The process group as the bench uses it: barrier, max over ranks, gather of small python objects."""
+
+    def __init__(self, world, rank, backend):
+        self.world, self.rank, self.backend = world, rank, backend
+        self.dist = None
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist:
+            self.dist.barrier()
+        if torch.cuda.is_available():   # (the CPU test of the rank logic has no device to wait for)
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if not self.dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, obj):
+        """every rank's object, in rank order (on every rank)"""
+        if not self.dist:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def setup(args):
+    world, rank, local = dist_env()
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
+        sys.exit(2)
+    ndev = torch.cuda.device_count()
+    # one process per GPU (nccl = RCCL).  gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks.
+    backend = os.environ.get("X265AMD_DIST_BACKEND", "nccl" if ndev >= world else "gloo")
+    dev_index = local if backend == "nccl" else local % ndev
+    torch.cuda.set_device(dev_index)
+    x265_amd.init(dev_index)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
+    return Group(world, rank, backend)
+
+
+# ------------------------------------------------------------------------------------------------
+# workload pieces
+# ------------------------------------------------------------------------------------------------
 def make_frames(nw, nh, ctu, rng, nframes, seed):
     """Nominal-size synthetic luma, edge-replicated to a multiple of the CTU (1080 -> 1088)."""
     seq = synth.make_sequence(nw, nh, nframes, search_range=rng, seed=seed)
     return np.stack([synth.pad_plane(f, ctu) for f in seq])
+
+
+def shard_of_sequence(nw, nh, ctu, rng, nrefs, fps, world, rank, seed=12345):
+    """ONE sequence of nrefs + world * fps frames (LCG seed 12345); this rank's run of `fps`
+    frames plus the nrefs frames before it.  The generator is sequential in time, so a rank generates the
+    prefix that ends with its own shard -- frame for frame what every other rank would generate for it."""
+    total = nrefs + world * fps
+    # shard_frames splits frames 1 .. n-1 of a sequence whose frame 0 is only a reference: with nrefs
+    # leading reference frames, frame index = nrefs - 1 + its index
+    sh = shard_frames(total - (nrefs - 1), world, rank, nrefs=1, segment=fps)
+    first = sh.first + nrefs - 1
+    assert sh.count == fps and first == nrefs + rank * fps
+    frames = make_frames(nw, nh, ctu, rng, first + fps, seed)
+    return frames[first - nrefs:], first
 
 
 def me_algorithmic_bytes(w, h, nctu, nrefs):
@@ -65,85 +177,218 @@ def me_algorithmic_bytes(w, h, nctu, nrefs):
     return w * h * (1 + nrefs) + nctu * nrefs * 8
 
 
+def legal_candidates(w, h, ctu, rng):
+    """sum over CTUs of the candidates that keep the block inside the picture (App. A.7)"""
+    n = 0
+    for cy in range(0, h, ctu):
+        ny = min(rng, cy) + min(rng, h - ctu - cy) + 1
+        for cx in range(0, w, ctu):
+            n += (min(rng, cx) + min(rng, w - ctu - cx) + 1) * ny
+    return n
+
+
+def evaluated_groups(pipe):
+    """One extra, untimed pass with the statistics variant of the elimination kernels: groups of four
+    candidates that got an exact SAD (first batch + second pass), summed over the batch."""
+    lib = x265_amd.api._lib()
+    stats = torch.zeros((pipe.nframes * pipe.nrefs, pipe.nctu, 16), dtype=torch.int32, device="cuda")
+    lib.x265amd_debug_set_me_stats(stats.data_ptr())
+    try:
+        pipe.motion_search()
+        torch.cuda.synchronize()
+    finally:
+        lib.x265amd_debug_set_me_stats(None)
+    s = stats.cpu().numpy().astype(np.int64)
+    return int(s[..., 0].sum() + s[..., 1].sum())
+
+
+def kernel_split(pipe, reps):
+    """per-kernel ms of the search stage: library-side HIP events on the launch stream"""
+    import ctypes
+    lib = x265_amd.api._lib()
+    lib.x265amd_debug_me_timing(1)
+    acc = np.zeros(4)
+    buf = (ctypes.c_float * 4)()
+    try:
+        for _ in range(reps):
+            pipe.motion_search()
+            if lib.x265amd_debug_me_last_ms(buf) != 0:
+                return None
+            acc += np.array(buf[:])
+    finally:
+        lib.x265amd_debug_me_timing(0)
+    return {k: round(float(v) / reps, 4) for k, v in zip(["box16_pairs", "_", "sea_bounds_kernel", "sea_exact_kernel"], acc)
+            if k != "_"}
+
+
+def worst_case(w, h, ctu, rng, nrefs, nominal_px):
+    """Content on which elimination cannot eliminate: white noise (bounds useless) and a flat picture (every
+    candidate ties).  Search stage only, 4 frames per launch, both entry points; identical output required."""
+    out = {}
+    g = np.random.default_rng(0)
+    nf = 4
+    for name, frames in (("noise", g.integers(0, 256, (nf + nrefs, h, w), dtype=np.uint8)),
+                         ("flat", np.full((nf + nrefs, h, w), 77, np.uint8))):
+        fr = torch.from_numpy(frames).cuda()
+        res = {}
+        keep = None
+        for method in ("sea", "brute"):
+            pipe = MeTqPipeline(fr, ctu=ctu, search_range=rng, nrefs=nrefs, method=method)
+            pipe.motion_search()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                pipe.motion_search()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            res[f"{method}_ms"] = round(ms, 4)
+            res[f"{method}_search_Mpixels_per_s"] = round(nominal_px * nf / (ms * 1e-3) / 1e6, 1)
+            mv = pipe.mv.clone()
+            if keep is None:
+                keep = mv
+            else:
+                res["identical_output"] = bool(torch.equal(keep, mv))
+            del pipe
+        out[name] = res
+    out["note"] = ("search stage only, 4 frames per launch; sea = x265amd_me_fullsearch_sea (the measured path), brute = "
+                   "x265amd_me_fullsearch (every candidate's SAD): nothing can be eliminated on this content, so the "
+                   "headline's rate does not apply to it")
+    return out
+
+
 def cpu_baseline(frames_np, ctu, rng, nrefs, tu, qp, gpu_mv, gpu_level, gpu_rec, nominal_px_per_frame):
-    """Reference (or port) ME on a deterministic sample of CTUs + TQ on one whole frame, on the
-    host cores; also the in-run parity check of the GPU result on that sample."""
+    """The reference (oracle/_ref, else the port) on the host cores: ME on a deterministic sample of CTUs,
+    TQ on one whole frame; all cores and one core.  Also the in-run parity check of the GPU result."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import pyoracle
     threads = min(16, os.cpu_count() or 1)
     orc = pyoracle.Oracle()
     kind = "port"
     me_lib = orc
+    ref = None
     if pyoracle.have_reference():
-        me_lib = pyoracle.Reference()
+        me_lib = ref = pyoracle.Reference()
         kind = "reference"
     h, w = frames_np.shape[1:]
     nctu = (h // ctu) * (w // ctu)
-    cur, ref = frames_np[nrefs], frames_np[nrefs - 1]
+    cur, prev = frames_np[nrefs], frames_np[nrefs - 1]
     # size the sample for ~10-30 core-seconds of CPU work: one CTU costs ~ (2R+1)^2 * ctu^2 / 0.7e9 s per core
     per_ctu = (2 * rng + 1) ** 2 * ctu * ctu / 0.7e9
     count = int(max(threads * 2, min(nctu, 30.0 / per_ctu)))
     step = max(nctu // count, 1)
     t0 = time.perf_counter()
-    mv = me_lib.me_fullsearch(cur, ref, ctu, rng, first=step // 2, step=step, count=count, nthreads=threads)
+    mv = me_lib.me_fullsearch(cur, prev, ctu, rng, first=step // 2, step=step, count=count, nthreads=threads)
     t_me = time.perf_counter() - t0
     idx = np.arange(step // 2, nctu, step)[:count]
     parity = bool((mv[idx] == gpu_mv[idx]).all())
-    # TQ on the whole frame with the GPU's vectors (identical to the CPU's where sampled)
+    # one core: a smaller sample of the same CTUs
+    n1 = max(2, min(len(idx), int(3.0 / per_ctu)))
     t0 = time.perf_counter()
-    lvl, sums = orc.tq_forward(cur, ref, tu, qp, 1, mv=gpu_mv, mv_ctu=ctu, nthreads=threads)
-    rec = orc.tq_inverse(lvl, ref, tu, qp, 1, mv=gpu_mv, mv_ctu=ctu, nthreads=threads)
-    t_tq = time.perf_counter() - t0
+    me_lib.me_fullsearch(cur, prev, ctu, rng, first=step // 2, step=step, count=n1, nthreads=1)
+    t_me1 = (time.perf_counter() - t0) / n1
+
+    # TQ on the whole frame with the GPU's vectors (identical to the CPU's where sampled).  The reference's
+    # xSubDct / xQuant / xDeQuant / xIDctAdd are single-threaded code: all cores = one CTU row of TUs per task.
+    def tq_ref_band(y0):
+        y1 = min(y0 + ctu, h)
+        ncx = w // ctu
+        return ref.tq_frame(cur[y0:y1], prev[y0:], tu, qp, 1, mv=gpu_mv[(y0 // ctu) * ncx:], mv_ctu=ctu)
+
+    if ref is not None:
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            bands = list(ex.map(tq_ref_band, range(0, h, ctu)))
+        t_tq = time.perf_counter() - t0
+        lvl = np.concatenate([b[0] for b in bands])
+        rec = np.concatenate([b[2] for b in bands])
+        t0 = time.perf_counter()
+        ref.tq_frame(cur, prev, tu, qp, 1, mv=gpu_mv, mv_ctu=ctu)
+        t_tq1 = time.perf_counter() - t0
+        tq_how = "oracle/_ref xSubDct + xQuant + xDeQuant + xIDctAdd, one CTU row per task"
+    else:
+        t0 = time.perf_counter()
+        lvl, _ = orc.tq_forward(cur, prev, tu, qp, 1, mv=gpu_mv, mv_ctu=ctu, nthreads=threads)
+        rec = orc.tq_inverse(lvl, prev, tu, qp, 1, mv=gpu_mv, mv_ctu=ctu, nthreads=threads)
+        t_tq = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        l1, _ = orc.tq_forward(cur, prev, tu, qp, 1, mv=gpu_mv, mv_ctu=ctu, nthreads=1)
+        orc.tq_inverse(l1, prev, tu, qp, 1, mv=gpu_mv, mv_ctu=ctu, nthreads=1)
+        t_tq1 = time.perf_counter() - t0
+        tq_how = "oracle port"
     parity = parity and bool((lvl == gpu_level).all()) and bool((rec == gpu_rec).all())
     sec_per_frame = t_me / len(idx) * nctu + t_tq
+    sec_per_frame_1 = t_me1 * nctu + t_tq1
     return {
         "value": round(nominal_px_per_frame / sec_per_frame / 1e6, 4),
         "unit": "Mpixels/s",
         "cores": threads,
         "kind": kind,
-        "sample": f"ME: {len(idx)} of {nctu} CTUs of one frame (every {step}th) in {t_me:.2f} s wall, scaled to the "
-                  f"frame; TQ fwd+inv: one whole frame in {t_tq:.3f} s ({'oracle/_ref xSadN loop' if kind == 'reference' else 'oracle port'} for ME, oracle port for TQ)",
+        "one_core_value": round(nominal_px_per_frame / sec_per_frame_1 / 1e6, 4),
+        "sample": f"ME: {len(idx)} of {nctu} CTUs of one frame (every {step}th) in {t_me:.2f} s wall on {threads} threads "
+                  f"({n1} of them on one core: {t_me1 * 1e3:.1f} ms per CTU), scaled to the frame "
+                  f"({'oracle/_ref xSadN loop' if kind == 'reference' else 'oracle port'}); TQ fwd+inv: one whole frame in "
+                  f"{t_tq:.3f} s on {threads} threads, {t_tq1:.3f} s on one core ({tq_how})",
         "parity_with_gpu_on_sample": parity,
     }
 
 
-def tq_only(args, world, rank, backend, nw, nh, ctu, fps, tu, qp):
+def sample_parity(frames_np, nrefs, ctu, rng, mv_np, first_frame, nsample=8):
+    """A few CTUs of this rank's first frame against the CPU checker (reference loop if built, else the port):
+    what rank 0 gathers from every rank of a multi-GPU run."""
+    from oracle import pyoracle
+    lib = pyoracle.Reference() if pyoracle.have_reference() else pyoracle.Oracle()
+    h, w = frames_np.shape[1:]
+    nctu = (h // ctu) * (w // ctu)
+    step = max(nctu // nsample, 1)
+    first = (first_frame * 7) % step
+    want = lib.me_fullsearch(frames_np[nrefs], frames_np[nrefs - 1], ctu, rng, first=first, step=step, count=nsample,
+                             nthreads=min(8, os.cpu_count() or 1))
+    idx = np.arange(first, nctu, step)[:nsample]
+    return bool((want[idx] == mv_np[0, 0][idx]).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def timed(grp, args, step_fn):
+    for _ in range(args.warmup):
+        step_fn()
+    grp.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step_fn(k)
+    grp.barrier()
+    return grp.max_over_ranks(time.perf_counter() - t0)
+
+
+def tq_only(args, grp, nw, nh, ctu, fps, tu, qp):
     """BASELINE configs[2]: the intra-style transform/quant path alone -- residual against the co-located
     block of the previous frame, forward transform + quant + dequant + inverse + reconstruction
     (x265amd_tq_roundtrip), SLICE_I rounding, no search."""
-    import torch.distributed as dist
-    frames_np = make_frames(nw, nh, ctu, 16, fps + 1, seed=12345 + 1000 * rank)
+    world, rank = grp.world, grp.rank
+    frames_np, first = shard_of_sequence(nw, nh, ctu, 16, 1, fps, world, rank)
     h, w = frames_np.shape[1:]
     frames = torch.from_numpy(frames_np).cuda()
     cur, pred = frames[1:], frames[:-1]
     level = torch.empty((fps, h, w), dtype=torch.int16, device="cuda")
     sums = torch.empty((fps, (h // tu) * (w // tu)), dtype=torch.int32, device="cuda")
     rec = torch.empty((fps, h, w), dtype=torch.uint8, device="cuda")
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
-    def step():
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
         x265_amd.tq_roundtrip(cur, pred, tu, qp, x265_amd.SLICE_I, out=(level, sums, rec))
+        if k is not None:
+            ev[k][1].record()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        step()
-    e1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(grp, args, step)
+    digest = hashlib.md5(level.cpu().numpy().tobytes() + rec.cpu().numpy().tobytes()).hexdigest()
+    digests = grp.gather({"rank": rank, "first_frame": first, "frames": fps, "level_rec_md5": digest})
     if rank == 0:
-        ms = e0.elapsed_time(e1) / args.steps
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         tq_bytes = 5 * w * h * fps
         out = {
             "metric": "TQ Mpixels/s", "value": round(nw * nh * fps * world * args.steps / elapsed / 1e6, 2),
@@ -152,12 +397,16 @@ def tq_only(args, world, rank, backend, nw, nh, ctu, fps, tu, qp):
             "vs_baseline": None, "dtype": "i32", "data": "synthetic",
             "config": {"workload": f"{nw}x{nh} 8-bit luma (padded {w}x{h}), {tu}x{tu} residual + DCT + quant + dequant + "
                                    f"IDCT + recon, QP{qp}, I-slice rounding, prediction = co-located block of the previous "
-                                   f"frame; {fps} frames per step per GPU", "name": args.workload, "tu": tu},
-            "roofline": {"kernel": f"tq_kernel<{tu}, 3>", "bound": "hbm", "achieved": round(tq_bytes / (ms * 1e-3) / 1e9, 2),
+                                   f"frame; {fps} frames per step per GPU, one sequence sharded across GPUs", "name": args.workload,
+                       "tu": tu},
+            "roofline": {"kernel": f"tq roundtrip kernel, {tu}x{tu}", "bound": "hbm",
+                         "achieved": round(tq_bytes / (ms * 1e-3) / 1e9, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tq_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         "traffic": None, "algorithmic_bytes_per_launch": tq_bytes, "avg_launch_ms": round(ms, 4)},
+                         "traffic": pmc_traffic(args.workload if tu == 32 else f"{args.workload}_tu{tu}", "tq_bytes_per_launch"),
+                         "algorithmic_bytes_per_launch": tq_bytes, "avg_launch_ms": round(ms, 4)},
+            "shards": digests,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.lean:
             from oracle import pyoracle
             orc = pyoracle.Oracle()
             threads = min(16, os.cpu_count() or 1)
@@ -165,53 +414,46 @@ def tq_only(args, world, rank, backend, nw, nh, ctu, fps, tu, qp):
             lvl, _ = orc.tq_forward(frames_np[1], frames_np[0], tu, qp, 0, nthreads=threads)
             orec = orc.tq_inverse(lvl, frames_np[0], tu, qp, 0, nthreads=threads)
             dt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": round(nw * nh / dt / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-                                   "sample": f"one whole frame, forward + inverse, in {dt:.3f} s (oracle port, OpenMP)",
-                                   "parity_with_gpu_on_sample": bool((lvl == level[0].cpu().numpy()).all()
-                                                                     and (orec == rec[0].cpu().numpy()).all())}
+            base = {"value": round(nw * nh / dt / 1e6, 2), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+                    "sample": f"one whole frame, forward + inverse, in {dt:.3f} s (oracle port, OpenMP)",
+                    "parity_with_gpu_on_sample": bool((lvl == level[0].cpu().numpy()).all()
+                                                      and (orec == rec[0].cpu().numpy()).all())}
+            if pyoracle.have_reference():
+                t0 = time.perf_counter()
+                rl, _, rr = pyoracle.Reference().tq_frame(frames_np[1], frames_np[0], tu, qp, 0)
+                dt1 = time.perf_counter() - t0
+                base["one_core_value"] = round(nw * nh / dt1 / 1e6, 2)
+                base["sample"] += f"; one core: the reference's own xSubDct/xQuant/xDeQuant/xIDctAdd (oracle/_ref) in {dt1:.3f} s"
+                base["parity_with_gpu_on_sample"] = base["parity_with_gpu_on_sample"] and bool(
+                    (rl == level[0].cpu().numpy()).all() and (rr == rec[0].cpu().numpy()).all())
+            out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
-def closed_loop(args, world, rank, backend, nw, nh, rng, nseg, qp):
+def closed_loop(args, grp, nw, nh, rng, nseg, qp):
     """Closed-loop P pictures (x265_amd.ClosedLoopGop): `nseg` independent GOP segments advance one picture per
     step -- search against the previous RECONSTRUCTION, luma 32x32 + chroma 16x16 transform / quant /
     reconstruction, reference rotation.  Pixels counted: luma of the nominal picture, like the main metric."""
-    import torch.distributed as dist
     from x265_amd import ClosedLoopGop
+    world, rank = grp.world, grp.rank
     T = 4
     w, h = nw, (nh + 63) // 64 * 64
     segs = []
-    for s_ in range(nseg):
-        y, u, v = synth.make_sequence(w, h, T, search_range=rng, seed=12345 + 1000 * rank + s_, chroma=True)
+    for s_ in range(nseg):   # GOP segments are the shard unit: segment id = rank * nseg + s_
+        y, u, v = synth.make_sequence(w, h, T, search_range=rng, seed=12345 + rank * nseg + s_, chroma=True)
         segs.append(np.concatenate([y.reshape(T, -1), u.reshape(T, -1), v.reshape(T, -1)], axis=1))
     yuv = torch.from_numpy(np.stack(segs)).cuda()          # [S][T][W*H*3/2]
     enc = ClosedLoopGop(w, h, nseg, search_range=rng, qp=qp)
     enc.set_reference(yuv[:, 0].contiguous())
     pics = [yuv[:, t].contiguous() for t in range(1, T)]
+    k = [0]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step(_k=None):
+        enc.encode_p(pics[k[0] % len(pics)])
+        k[0] += 1
 
-    k = 0
-    for _ in range(args.warmup):
-        enc.encode_p(pics[k % len(pics)])
-        k += 1
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        enc.encode_p(pics[k % len(pics)])
-        k += 1
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed(grp, args, step)
     if rank == 0:
         print(json.dumps({
             "metric": "closed-loop ME+TQ Mpixels/s", "value": round(nw * nh * nseg * world * args.steps / elapsed / 1e6, 2),
@@ -223,128 +465,81 @@ def closed_loop(args, world, rank, backend, nw, nh, rng, nseg, qp):
                                    f"16x16 TQ + reconstruction QP{qp}, reference rotation", "name": args.workload,
                        "me_method": enc.method},
         }), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
-    ap.add_argument("--me-method", default="sea", choices=["sea", "brute"],
-                    help="sea: exact successive elimination (default); brute: every candidate's SAD. Same output.")
-    ap.add_argument("--tu", type=int, default=None, choices=[4, 8, 16, 32], help="transform size (default: the workload's)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def pmc_traffic(key, field):
+    """HBM-side bytes per launch from the PMC passes committed under profiles/ (tools/run_pmc.sh; separate
+    --pmc runs, gfx950 corrections): counters cannot be collected inside this run."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(key, {}).get(field)
+    except Exception:
+        return None
 
-    world, rank, local = dist_env()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torchrun (one process per GPU); see the module docstring",
-                  file=sys.stderr)
-            sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py: no GPU visible; the hot path has no CPU fallback", file=sys.stderr)
-        sys.exit(2)
-    # one process per GPU.  X265AMD_DIST_BACKEND=gloo is for rehearsing the multi-rank path on a box with
-    # fewer GPUs than ranks (ranks then share devices); the driver's runs use nccl (= RCCL).
-    backend = os.environ.get("X265AMD_DIST_BACKEND", "nccl")
-    dev_index = local if backend == "nccl" else local % torch.cuda.device_count()
-    torch.cuda.set_device(dev_index)
-    x265_amd.init(dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend)
 
-    nw, nh, ctu, rng, nrefs, fps, tu, qp = WORKLOADS[args.workload]
-    tu = args.tu or tu
-    if args.workload == "tq1080p":
-        return tq_only(args, world, rank, backend, nw, nh, ctu, fps, tu, qp)
-    if args.workload == "gop1080p":
-        return closed_loop(args, world, rank, backend, nw, nh, rng, fps, qp)
-    frames_np = make_frames(nw, nh, ctu, rng, fps + nrefs, seed=12345 + 1000 * rank)
+def search_and_tq(args, grp, nw, nh, ctu, rng, nrefs, fps, tu, qp):
+    world, rank = grp.world, grp.rank
+    frames_np, first = shard_of_sequence(nw, nh, ctu, rng, nrefs, fps, world, rank)
     h, w = frames_np.shape[1:]
     frames = torch.from_numpy(frames_np).cuda()
     pipe = MeTqPipeline(frames, ctu=ctu, search_range=rng, nrefs=nrefs, tu=tu, qp=qp, method=args.me_method)
     nctu = pipe.nctu
+    ev = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for _ in range(args.steps)]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        pipe.step()
-    barrier()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for k in range(args.steps):
+    def step(k=None):
+        if k is None:
+            return pipe.step()
         ev[k][0].record()
         pipe.motion_search()
         ev[k][1].record()
         pipe.transform_quant()
         ev[k][2].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    elapsed = timed(grp, args, step)
     me_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     tq_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
 
-    # per-kernel split of the search stage (library-side HIP events on the launch stream), taken right
-    # after the timed region on a few more passes of the same batch: the events are read back per pass
-    kernels_ms = None
-    if pipe.method == "sea" and rank == 0:
-        import ctypes
-        lib = x265_amd.api._lib()
-        lib.x265amd_debug_me_timing.argtypes = [ctypes.c_int]
-        lib.x265amd_debug_me_last_ms.argtypes = [ctypes.POINTER(ctypes.c_float)]
-        lib.x265amd_debug_me_timing(1)
-        acc = np.zeros(4)
-        reps = min(args.steps, 10)
-        buf = (ctypes.c_float * 4)()
-        for _ in range(reps):
-            pipe.motion_search()
-            if lib.x265amd_debug_me_last_ms(buf) != 0:
-                acc[:] = np.nan
-                break
-            acc += np.array(buf[:])
-        lib.x265amd_debug_me_timing(0)
-        kernels_ms = dict(zip(["box16_pairs", "_", "sea_bounds_kernel", "sea_exact_kernel"],
-                              [round(float(x) / reps, 4) for x in acc]))
-        kernels_ms.pop("_", None)
+    # every rank: digest of its results + a small sample of its own first frame against the CPU checker
+    torch.cuda.synchronize()
+    mv_np = x265_amd.mv_to_numpy(pipe.mv)
+    shard = {"rank": rank, "first_frame": first, "frames": fps,
+             "mv_md5": hashlib.md5(mv_np.tobytes()).hexdigest(),
+             "level_rec_md5": hashlib.md5(pipe.level.cpu().numpy().tobytes() + pipe.rec.cpu().numpy().tobytes()).hexdigest()}
+    if world > 1:
+        shard["sample_parity_vs_cpu"] = sample_parity(frames_np, nrefs, ctu, rng, mv_np, first)
+    shards = grp.gather(shard)
 
     if rank == 0:
+        kernels_ms = kernel_split(pipe, min(args.steps, 10)) if pipe.method == "sea" else None
         px_step = nw * nh * fps                      # nominal pixels (1920x1080), SURVEY.md 8d
         value = px_step * world * args.steps / elapsed / 1e6
         me_bytes = me_algorithmic_bytes(w, h, nctu, nrefs) * fps
         achieved = me_bytes / (me_ms * 1e-3) / 1e9
         tq_bytes = 5 * w * h * fps                   # src + pred + 2 B level + rec
-        sad_ops = 0
-        ncx = w // ctu
-        for i in range(nctu):  # legal candidates per CTU (clamped at the picture edge)
-            cx, cy = (i % ncx) * ctu, (i // ncx) * ctu
-            nx = min(rng, cx) + min(rng, w - ctu - cx) + 1
-            ny = min(rng, cy) + min(rng, h - ctu - cy) + 1
-            sad_ops += nx * ny
-        sad_ops *= ctu * ctu * nrefs * fps
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                with open(pmc) as f:
-                    traffic = json.load(f).get(args.workload, {}).get("me_bytes_per_launch")
-            except Exception:
-                traffic = None
+        exhaustive = legal_candidates(w, h, ctu, rng) * ctu * ctu * nrefs * fps
+        valu = {"peak_Tpx_sad_per_s": QSAD_PEAK_TPX,
+                "peak_source": "tools/ubench_valu: v_qsad_pk_u16_u8 issue rate on this chip (profiles/ubench_r1.txt)",
+                "exhaustive_pixel_sads_per_launch": exhaustive,
+                "exhaustive_equivalent_Tpx_sad_per_s": round(exhaustive / (me_ms * 1e-3) / 1e12, 3)}
+        if pipe.method == "sea" and not args.lean:
+            groups = evaluated_groups(pipe)
+            ev_sads = groups * 4 * ctu * ctu         # a group = four candidates, each a full 64x64 SAD
+            valu.update({
+                "evaluated_pixel_sads_per_launch": ev_sads,
+                "evaluated_fraction_of_exhaustive": round(ev_sads / exhaustive, 5),
+                "achieved_Tpx_sad_per_s": round(ev_sads / (me_ms * 1e-3) / 1e12, 3),
+                "frac": round(ev_sads / (me_ms * 1e-3) / 1e12 / QSAD_PEAK_TPX, 4),
+                "frac_exact_kernel_alone": round(ev_sads / (kernels_ms["sea_exact_kernel"] * 1e-3) / 1e12 / QSAD_PEAK_TPX, 4)
+                if kernels_ms else None,
+                "note": "achieved = pixel-SADs the elimination search actually evaluated (statistics variant of the "
+                        "kernels, one extra untimed pass) / search-stage time: the stage's real qsad issue rate against "
+                        "the measured issue peak.  exhaustive_equivalent = what an every-candidate search would have "
+                        "had to evaluate / the same time (an effective rate, not a utilisation)"})
+        elif pipe.method == "brute":
+            valu.update({"achieved_Tpx_sad_per_s": valu["exhaustive_equivalent_Tpx_sad_per_s"],
+                         "frac": round(valu["exhaustive_equivalent_Tpx_sad_per_s"] / QSAD_PEAK_TPX, 4)})
         out = {
             "metric": "ME+TQ Mpixels/s",
             "value": round(value, 2),
@@ -360,37 +555,66 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{nw}x{nh} 8-bit luma (padded {w}x{h}), {ctu}x{ctu} CTU, +-{rng} integer-pel "
                                    f"full search, {nrefs} ref(s), then {tu}x{tu} DCT+quant+recon QP{qp}; "
-                                   f"{fps} frames per step per GPU, frames sharded across GPUs, no collective",
-                       "name": args.workload, "frames_per_step_per_gpu": fps, "me_method": pipe.method},
+                                   f"{fps} frames per step per GPU, one sequence of {world * fps} frames sharded across "
+                                   f"GPUs (x265_amd.shard_frames), no collective",
+                       "name": args.workload, "frames_per_step_per_gpu": fps, "me_method": pipe.method,
+                       "dist_backend": grp.backend if world > 1 else None},
             "roofline": {"kernel": "search stage = box16_pairs + sea_bounds_kernel + sea_exact_kernel (dominant)"
                                    if pipe.method == "sea" else "me_fullsearch_qsad",
-                         "bound": "hbm", "achieved": round(achieved, 3),
+                         "bound": "hbm", "binding_resource": "valu (v_qsad_pk_u16_u8 issue; see valu)",
+                         "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": me_bytes,
+                         "traffic": pmc_traffic(args.workload, "me_bytes_per_launch"),
+                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command, tools/run_pmc.sh)",
+                         "algorithmic_bytes_per_launch": me_bytes,
                          "avg_launch_ms": round(me_ms, 4), "kernels_ms": kernels_ms,
                          "note": "avg_launch_ms = the whole search stage per step (sum of its kernels; compare the "
                                  "sum of their averages in profiles/*kernel_stats.csv).  Exhaustive SAD search is "
-                                 "integer-VALU bound, not HBM bound (SURVEY.md 8d); see valu.  traffic = PMC "
-                                 "FETCH_SIZE (x2, gfx950) + WRITE_SIZE over the stage's kernels "
-                                 "(profiles/pmc_traffic.json); it counts fabric requests, Infinity-Cache hits "
-                                 "included (window overlap between neighbouring CTUs, box-sum workspace)"},
-            "valu": {"pixel_sads_per_launch": sad_ops, "achieved_Tpx_sad_per_s": round(sad_ops / (me_ms * 1e-3) / 1e12, 3),
-                     "peak_Tpx_sad_per_s": 152.0,
-                     "peak_source": "tools/ubench_valu: v_qsad_pk_u16_u8 issue rate on this chip (profiles/ubench_r1.txt)"},
+                                 "integer-VALU bound, not HBM bound (SURVEY.md 8d): `valu` is its roofline.  traffic "
+                                 "counts fabric requests, Infinity-Cache hits included (window overlap between "
+                                 "neighbouring CTUs, box-sum workspace)"},
+            "valu": valu,
             "roofline_tq": {"kernel": "tq_roundtrip", "bound": "hbm", "achieved": round(tq_bytes / (tq_ms * 1e-3) / 1e9, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(tq_bytes / (tq_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                            "traffic": pmc_traffic(args.workload, "tq_bytes_per_launch"),
                             "algorithmic_bytes_per_launch": tq_bytes, "avg_launch_ms": round(tq_ms, 4)},
+            "shards": shards,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            torch.cuda.synchronize()
-            gmv = x265_amd.mv_to_numpy(pipe.mv)[0, 0]
+        if world == 1 and not args.lean:
+            gmv = mv_np[0, 0]
             out["cpu_baseline"] = cpu_baseline(frames_np, ctu, rng, nrefs, tu, qp, gmv, pipe.level[0].cpu().numpy(),
                                                pipe.rec[0].cpu().numpy(), nw * nh)
+            if args.workload == "1080p":
+                out["worst_case"] = worst_case(w, h, ctu, rng, nrefs, nw * nh)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    grp.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--me-method", default="sea", choices=["sea", "brute"],
+                    help="sea: exact successive elimination (default); brute: every candidate's SAD. Same output.")
+    ap.add_argument("--tu", type=int, default=None, choices=[4, 8, 16, 32], help="transform size (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", "--lean", dest="lean", action="store_true",
+                    help="timed region only: no CPU baseline, no statistics pass, no worst-case sub-line (profiler runs)")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))     # nothing in this process has touched the GPU
+    grp = setup(args)
+    nw, nh, ctu, rng, nrefs, fps, tu, qp = WORKLOADS[args.workload]
+    tu = args.tu or tu
+    if args.workload == "tq1080p":
+        return tq_only(args, grp, nw, nh, ctu, fps, tu, qp)
+    if args.workload == "gop1080p":
+        return closed_loop(args, grp, nw, nh, rng, fps, qp)
+    return search_and_tq(args, grp, nw, nh, ctu, rng, nrefs, fps, tu, qp)
 
 
 if __name__ == "__main__":
