@@ -31,6 +31,11 @@ int x265amd_debug_me_last_ms(float *out4);
  * wave count (8 or 16; 0 = the library's choice) */
 void x265amd_debug_sea_shape(int lds_pad_bytes, int waves);
 
+/* transform / quantisation path: 0 = the library's choice (integer matrix products, tq_mfma.hip, wherever one
+ * matrix serves the whole plane), 1 = always the LDS-resident partial-butterfly kernel (tq_kernels.hip) -- the
+ * two are independent formulations of the same arithmetic and must agree bit for bit */
+void x265amd_debug_tq_path(int path);
+
 /* x265amd_me_fullsearch in its independent one-candidate-per-lane formulation (v_alignbyte_b32 + v_sad_u8,
  * current block in LDS): the cross-check of the production kernels, 1.0-1.6 Gpix/s */
 int x265amd_debug_me_fullsearch_basic(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height, int stride,

@@ -1,0 +1,23 @@
+// tq_common.h -- what the two implementations of the transform / quantisation path share
+// (tq_kernels.hip: LDS-resident partial butterflies on the VALU; tq_mfma.hip: integer matrix products)
+#pragma once
+#include "common.h"
+
+namespace x265amd {
+
+struct TqParams {
+    x265amd_tq_desc d;
+    int tiles_x, tiles_y, ntiles;  // 32x32 pixel tiles
+    // quantiser constants (src/pixel.cpp:595-602, 638-644), computed once on the host
+    unsigned q_scale;
+    int q_bits;
+    unsigned q_rnd;
+    int dq_scale, dq_shift, dq_rnd;
+};
+
+enum { TQ_FWD = 1, TQ_INV = 2, TQ_BOTH = 3 };
+
+// tq_mfma.hip: all TU sizes; the 4x4 DST (per-TU intra modes) stays with the butterfly kernel
+int launch_tq_mfma(int mode, const TqParams &p, hipStream_t stream);
+
+}  // namespace x265amd

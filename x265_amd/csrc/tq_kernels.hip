@@ -19,18 +19,9 @@
 // MFMA is deliberately not used: every sum must equal the reference's Int32 sum.
 #include "common.h"
 #include "hevc_transform.h"
+#include "tq_common.h"
 
 namespace x265amd {
-
-struct TqParams {
-    x265amd_tq_desc d;
-    int tiles_x, tiles_y, ntiles;
-    // quantiser constants (src/pixel.cpp:595-602, 638-644), computed once on the host
-    unsigned q_scale;
-    int q_bits;
-    unsigned q_rnd;
-    int dq_scale, dq_shift, dq_rnd;
-};
 
 struct __attribute__((packed, aligned(1))) U128 {
     uint32_t v[4];
@@ -38,8 +29,6 @@ struct __attribute__((packed, aligned(1))) U128 {
 struct __attribute__((packed, aligned(1))) U32 {
     uint32_t v;
 };
-
-enum { TQ_FWD = 1, TQ_INV = 2, TQ_BOTH = 3 };
 
 constexpr int kPitch = 34;  // Int16 elements per LDS row: 17 dwords (odd) => conflict-free both ways
 
@@ -402,6 +391,9 @@ static void quant_constants(int tu, int qp, int slice_type, TqParams &p)
     p.dq_scale = kInvQuantScales[qp % 6] << (qp / 6);
 }
 
+// debugging aid (include/x265_amd_debug.h): 0 = the library's choice, 1 = always the butterfly kernel
+static int g_tq_path = 0;
+
 template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_t stream, bool coef_in = false)
 {
     if (!initialised()) return X265AMD_ERR_NOT_INIT;
@@ -433,6 +425,9 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
         p.dq_rnd = 0;
         p.dq_shift = 0;
     }
+    // the matrix-core formulation (tq_mfma.hip) wherever the transform matrix is the same for every TU of the
+    // plane; per-TU DST selection at 4x4 (d_modes) and the debug switch keep the butterfly kernel
+    if (g_tq_path != 1 && !(d.tu == 4 && d.d_modes)) return launch_tq_mfma(MODE, p, stream);
     const dim3 grid((unsigned)((nt + 7) / 8)), block(256);
     switch (d.tu) {
     case 4: hipLaunchKernelGGL((tq_kernel<4, MODE>), grid, block, 0, stream, p); break;
@@ -446,6 +441,8 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
 }  // namespace x265amd
 
 using namespace x265amd;
+
+extern "C" void x265amd_debug_tq_path(int path) { g_tq_path = path; }
 
 extern "C" int x265amd_tq_forward(const x265amd_tq_desc *desc, void *stream)
 {

@@ -1,0 +1,388 @@
+// tq_mfma.hip -- the transform / quantisation path on the matrix cores, bit-exact.
+//
+// Replaces xSubDct / xQuant / xDeQuant / xIDctAdd (src/pixel.cpp:591-776) for whole picture planes, like
+// tq_kernels.hip, with the four 1-D transform passes as INTEGER matrix products:
+// v_mfma_i32_32x32x32_i8 multiplies signed bytes and accumulates in Int32, and integer addition is
+// associative modulo 2^32, so a matrix product returns exactly the reference's Int32 sums
+// (sum_j T[k][j] * x[j], src/pixel.cpp:114-312 / 321-569) whatever order the hardware adds in.  (The
+// north_star's "MFMA is not used because the transform must be bit-exact" holds for the floating-point
+// matrix instructions; the i8 form is exact.)  The HEVC matrices are Int8 by definition
+// (g_aiT4/8/16/32, src/table.cpp:72-145); the data are not, so each pass splits them into byte planes:
+//   forward pass 1 : residual = src - pred = (src - 128) + (127 - pred) + 1: two products with signed
+//                    bytes, K = 2 x 32; the "+ 1" adds 64 N to the DC column before the shift, = +128 after
+//                    it, which pass 2 turns into +128 on the TU's DC coefficient -- added there;
+//   other passes   : Int16 data x = 256 H + (L' + 128), H = x >> 8 (signed byte), L' = (x & 255) - 128:
+//                    sum = 256 (T.H) + T.L' + 128 (T.1).  T.1 is 64 N on DC rows and 0 elsewhere for the forward
+//                    matrix; for the inverse it is the column sums of T: constants, folded into the accumulator
+//                    start values.
+// A 32x32 pixel tile per wave; TUs smaller than 32 use block-diagonal matrices (same instruction, zeros
+// off the diagonal).  Each product's result is laid out by the hardware as "column on the lane, rows in
+// the 16 accumulator registers"; the next pass sums over exactly those rows, so all four passes chain in
+// registers: no LDS, no transposes (the fragment of the constant matrix is permuted instead).
+//   src/pred rows (lane = row)  --pass 1-->  M1 (lane = kx, regs = y)  --pass 2-->  coefficients
+//   (lane = x, regs = y: quantised, stored)  --dequant, inverse 1-->  (lane = y, regs = kx)  --inverse 2-->
+//   residual (lane = y, regs = x)  + pred, clip  -->  16-byte row stores.
+// The element-wise work between the products (round, shift, split into bytes, quantise, dequantise,
+// clip) is what is left on the VALU: ~23 instructions per pixel-register instead of the butterflies' ~67.
+#include "common.h"
+#include "hevc_transform.h"
+#include "tq_common.h"
+
+namespace x265amd {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---- compile-time ROM ------------------------------------------------------------------------------
+constexpr int kCosMagTab[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4,  0};
+constexpr int tcoef(int n, int k, int j)  // T_n[k][j], as Coef<n, k, j>::value
+{
+    const int a0 = ((k * (32 / n)) * (2 * j + 1)) & 127;
+    const int a1 = a0 > 64 ? 128 - a0 : a0;
+    return a1 <= 32 ? kCosMagTab[a1] : -kCosMagTab[64 - a1];
+}
+static_assert(tcoef(32, 1, 0) == Coef<32, 1, 0>::value && tcoef(32, 31, 5) == Coef<32, 31, 5>::value &&
+                  tcoef(16, 3, 7) == Coef<16, 3, 7>::value && tcoef(8, 5, 2) == Coef<8, 5, 2>::value &&
+                  tcoef(4, 3, 1) == Coef<4, 3, 1>::value && tcoef(4, 2, 3) == Coef<4, 2, 3>::value,
+              "ROM generators disagree");
+// the 32x32 block-diagonal matrix of (32/n)^2 transforms of size n
+constexpr int tblock(int n, int k, int j) { return k / n == j / n ? tcoef(n, k % n, j % n) : 0; }
+// row of the product held by accumulator register r of a lane in half h (v_mfma_*_32x32: C/D layout)
+__host__ __device__ constexpr int rho(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct FragSet {             // per lane (n = lane & 31, h = lane >> 5): 16 bytes of the constant operand
+    int8_t f1[64][16];       // T[n][16 h + j]      forward pass 1 (B operand; data rows are read 16 bytes per lane)
+    int8_t f2[64][16];       // T[n][rho(j, h)]     forward pass 2 (A operand; data = previous accumulators)
+    int8_t f3[64][16];       // T[rho(j, h)][n]     both inverse passes
+    int32_t kappa[32];       // 128 * sum_k T[k][n]: what the "+ 128" of the low data bytes adds to inverse output n
+};
+constexpr FragSet make_frags(int n)
+{
+    FragSet f = {};
+    for (int l = 0; l < 64; l++)
+        for (int j = 0; j < 16; j++) {
+            const int c = l & 31, h = l >> 5;
+            f.f1[l][j] = (int8_t)tblock(n, c, 16 * h + j);
+            f.f2[l][j] = (int8_t)tblock(n, c, rho(j, h));
+            f.f3[l][j] = (int8_t)tblock(n, rho(j, h), c);
+        }
+    for (int c = 0; c < 32; c++) {
+        int s = 0;
+        for (int k = 0; k < 32; k++) s += tblock(n, k, c);
+        f.kappa[c] = 128 * s;
+    }
+    return f;
+}
+__device__ const FragSet kFrags[4] = {make_frags(4), make_frags(8), make_frags(16), make_frags(32)};
+
+// ---- small helpers ---------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(1))) P128 {
+    uint32_t v[4];
+};
+struct __attribute__((packed, aligned(1))) P32 {
+    uint32_t v;
+};
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+__device__ __forceinline__ v4i as_v4i(const uint32_t (&w)[4]) { return v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}; }
+__device__ __forceinline__ v16i splat16(int v) { return v16i{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v}; }
+__device__ __forceinline__ v16i mfma(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+
+// four values whose low 16 bits are wanted -> (high bytes, low bytes - 128) as the two operand dwords
+__device__ __forceinline__ void split4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &hi, uint32_t &lo)
+{
+    const uint32_t ab = perm(b, a, 0x05010400u), cd = perm(d, c, 0x05010400u);  // a0 b0 a1 b1
+    lo = perm(cd, ab, 0x05040100u) ^ 0x80808080u;
+    hi = perm(cd, ab, 0x07060302u);
+}
+// two Int16 pairs {b, a}, {d, c} -> the same
+__device__ __forceinline__ void split2x2(uint32_t ba, uint32_t dc, uint32_t &hi, uint32_t &lo)
+{
+    lo = perm(dc, ba, 0x06040200u) ^ 0x80808080u;
+    hi = perm(dc, ba, 0x07050301u);
+}
+__device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t pair)  // {sat8(hi), sat8(lo)} in bits [15:0]
+{
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(pair));
+    return r;
+}
+__device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc)  // |a - b| + acc: v_sad_u32
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ void swap32(uint32_t &x, uint32_t &y)  // x's upper half-wave <-> y's lower half-wave
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0];
+    y = r[1];
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------
+// One wave = one 32x32 tile at a time; a workgroup's four waves take four tiles that are neighbours in x.
+template <int N, int MODE>
+__global__ __launch_bounds__(256) void tq_mfma_kernel(const TqParams p)
+{
+    constexpr int L2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
+    constexpr int FI = L2 - 2;
+    constexpr int sh1 = L2 - 1, sh2 = L2 + 6;
+    const x265amd_tq_desc &d = p.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+
+    // constant operands of this lane
+    const FragSet &F = kFrags[FI];
+    const v4i f1 = *reinterpret_cast<const v4i *>(F.f1[lane]);
+    const v4i f2 = *reinterpret_cast<const v4i *>(F.f2[lane]);
+    const v4i f3 = *reinterpret_cast<const v4i *>(F.f3[lane]);
+    v16i cin_i1, cin_i2;  // accumulator starts of the inverse passes: rounding + the low-byte bias
+    if constexpr (MODE & TQ_INV) {
+        const int k1 = 64 + F.kappa[c];  // SHIFT_INV_1ST = 7; output index = the lane
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            cin_i1[r] = k1;
+            cin_i2[r] = 2048 + F.kappa[rho(r, h)];  // SHIFT_INV_2ND = 12; output index = the register's row
+        }
+    }
+    // xQuant (src/pixel.cpp:595-616) in signed form: level = (c Q + rnd + (c < 0 ? 2^qbits - 1 - 2 rnd : 0)) >> qbits
+    // equals sign(c) ((|c| Q + rnd) >> qbits); 2^30 on top keeps the sum positive, so the shift is logical and
+    // level + 2^(30 - qbits) comes out: |level| is then one v_sad_u32 away.
+    const int q_pos = (int)p.q_rnd + (1 << 30);
+    const int q_neg = q_pos + (int)((1u << p.q_bits) - 1u - 2u * p.q_rnd);
+    const uint32_t q_bias = 1u << (30 - p.q_bits);
+    // the "+ 1" of pass 1 and the "+ 128" of pass 2's low bytes, both on DC rows only (header comment)
+    const int dc_corr = (N == 4 || h == 0) ? ((1 + ((c & (N - 1)) == 0 ? 1 : 0)) << (13 + L2)) : 0;
+
+    const int tpf = p.tiles_x * p.tiles_y;
+    const int tus_x = d.width / N;
+    for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles; tile += gridDim.x * 4) {
+        const int f = tile / tpf;
+        const int trem = tile - f * tpf;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int x0 = tx * 32, y0 = ty * 32;
+        const int wvalid = min(32, d.width - x0), hvalid = min(32, d.height - y0);  // multiples of N
+        const bool full = wvalid == 32 && hvalid == 32;
+
+        // ---- the lane's 16 bytes of its picture row: prediction (kept for the reconstruction) and source ----
+        const bool row_ok = c < hvalid;           // lane = row c of the tile, bytes 16 h .. 16 h + 15
+        const int xh = x0 + 16 * h, y = y0 + c;
+        uint32_t predw[4] = {0u, 0u, 0u, 0u};
+        if (row_ok && 16 * h < wvalid) {
+            const uint8_t *pp = d.d_pred + (int64_t)f * d.pred_frame_stride;
+            const uint8_t *q;
+            if (d.d_mv) {  // integer-pel motion compensation fused into the load; mv_ctu >= 16: one vector per half row
+                const x265amd_mv m = d.d_mv[(int64_t)f * d.mv_frame_stride + (y / d.mv_ctu) * (d.width / d.mv_ctu) + xh / d.mv_ctu];
+                q = pp + (int64_t)(y + (m.mvy >> d.mv_shift)) * d.pred_stride + xh + (m.mvx >> d.mv_shift);
+            } else {
+                q = pp + (int64_t)y * d.pred_stride + xh;
+            }
+            if (xh + 16 <= d.width) {
+                const P128 a = *reinterpret_cast<const P128 *>(q);
+#pragma unroll
+                for (int i = 0; i < 4; i++) predw[i] = a.v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    if (xh + 4 * i < d.width) predw[i] = reinterpret_cast<const P32 *>(q + 4 * i)->v;
+            }
+        }
+
+        int level[16];  // the lane's column of quantised levels: x = x0 + c, y = y0 + rho(r, h)
+        const bool col_ok = c < wvalid;
+        if constexpr (MODE & TQ_FWD) {
+            uint32_t srcw[4] = {0u, 0u, 0u, 0u};
+            if (row_ok && 16 * h < wvalid) {
+                const uint8_t *q = d.d_src + (int64_t)f * d.src_frame_stride + (int64_t)y * d.src_stride + xh;
+                if (xh + 16 <= d.width) {
+                    const P128 a = *reinterpret_cast<const P128 *>(q);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) srcw[i] = a.v[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (xh + 4 * i < d.width) srcw[i] = reinterpret_cast<const P32 *>(q + 4 * i)->v;
+                }
+            }
+            // ================= pass 1: residual x T^T (rows of the tile) =================
+            uint32_t sa[4], pa[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                sa[i] = srcw[i] ^ 0x80808080u;   // src - 128
+                pa[i] = predw[i] ^ 0x7f7f7f7fu;  // 127 - pred
+            }
+            v16i acc = mfma(as_v4i(sa), f1, splat16(1 << (sh1 - 1)));
+            acc = mfma(as_v4i(pa), f1, acc);
+            // (sum + rnd) >> sh1, truncating Int16 store (src/pixel.cpp:126-129) -- minus the 128 of the header
+            // comment on DC columns; split into bytes for the next product
+            uint32_t mh[4], ml[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+                split4((uint32_t)acc[4 * g] >> sh1, (uint32_t)acc[4 * g + 1] >> sh1, (uint32_t)acc[4 * g + 2] >> sh1,
+                       (uint32_t)acc[4 * g + 3] >> sh1, mh[g], ml[g]);
+            // ================= pass 2: T x M1 (columns) =================
+            constexpr int rnd2 = 1 << (sh2 - 1);
+            v16i ah = mfma(f2, as_v4i(mh), splat16(N >= 8 ? rnd2 >> 8 : 0));  // 256 * (rnd2 >> 8) = rnd2 for N >= 8
+            v16i al = mfma(f2, as_v4i(ml), splat16(0));
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if ((rho(r, 0) & (N - 1)) == 0) al[r] += dc_corr;  // rho(r, 1) = rho(r, 0) + 4: a DC row too iff N == 4
+            int16_t *lvp = d.d_level + (int64_t)f * d.level_frame_stride + (int64_t)y0 * d.level_stride + x0 + c;
+            int16_t *cfp = d.d_coef ? d.d_coef + (int64_t)f * d.level_frame_stride + (int64_t)y0 * d.level_stride + x0 + c : nullptr;
+            uint32_t psum[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int t = (int)(((uint32_t)ah[r] << 8) + (uint32_t)al[r]);
+                if constexpr (N == 4) t += rnd2;
+                const int cf = __builtin_amdgcn_sbfe(t, sh2, 16);  // truncating Int16 store of the coefficient
+                // xQuant
+                const int q = mul24(cf, (int)p.q_scale) + (cf < 0 ? q_neg : q_pos);
+                const uint32_t lb = (uint32_t)q >> p.q_bits;   // level + q_bias
+                psum[r >> 2] = sad_u32(lb, q_bias, psum[r >> 2]);
+                level[r] = (int)(lb - q_bias);
+                const int yy = rho(r, h);
+                if (full || (col_ok && yy < hvalid)) {
+                    lvp[(int64_t)yy * d.level_stride] = (int16_t)level[r];
+                    if (cfp) cfp[(int64_t)yy * d.level_stride] = (int16_t)cf;
+                }
+            }
+            if (d.d_abs_sum) {
+                // xQuant's return value per TU: registers 4q .. 4q+3 are rows 8q + 4h .. + 3
+                uint32_t s[4];
+                int ns;
+                if constexpr (N == 32) {
+                    s[0] = psum[0] + psum[1] + psum[2] + psum[3];
+                    ns = 1;
+                } else if constexpr (N == 16) {
+                    s[0] = psum[0] + psum[1];
+                    s[1] = psum[2] + psum[3];
+                    ns = 2;
+                } else {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; q4++) s[q4] = psum[q4];
+                    ns = 4;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    if (i >= ns) break;
+#pragma unroll
+                    for (int o = 1; o < N && o < 32; o <<= 1) s[i] += __shfl_xor(s[i], o);
+                    if constexpr (N >= 8) s[i] += __shfl_xor(s[i], 32);
+                }
+                if ((c & (N - 1)) == 0 && (N == 4 || h == 0) && col_ok) {
+                    uint32_t *ap = d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride + (int64_t)(y0 / N) * tus_x + (x0 + c) / N;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (i >= ns) break;
+                        const int tuy = N == 4 ? 2 * i + h : i;  // TU row inside the tile
+                        if (tuy * N < hvalid) ap[(int64_t)tuy * tus_x] = s[i];
+                    }
+                }
+            }
+        } else {
+            const int16_t *lvp = d.d_level + (int64_t)f * d.level_frame_stride + (int64_t)y0 * d.level_stride + x0 + c;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int yy = rho(r, h);
+                level[r] = (full || (col_ok && yy < hvalid)) ? (int)lvp[(int64_t)yy * d.level_stride] : 0;
+            }
+        }
+
+        if constexpr (MODE & TQ_INV) {
+            // ================= xDeQuant (src/pixel.cpp:649-650): clip16((level * scale + rnd) >> shift) =================
+            uint32_t dh[4], dl[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                int v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = (mul24(level[4 * g + k], p.dq_scale) + p.dq_rnd) >> p.dq_shift;
+                // v_cvt_pk_i16_i32 saturates: the clip and the pack in one
+                const uint32_t p0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0], v[1]));
+                const uint32_t p1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2], v[3]));
+                split2x2(p0, p1, dh[g], dl[g]);
+            }
+            // ================= inverse pass 1 (columns): coefficients^T x T =================
+            v16i ah = mfma(as_v4i(dh), f3, splat16(0));
+            v16i al = mfma(as_v4i(dl), f3, cin_i1);
+            // (sum + 64) >> 7, store-then-clip = wrap (src/pixel.cpp:334-342); lane = picture row now
+            uint32_t uh[4], ul[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                uint32_t t[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) t[k] = (((uint32_t)ah[4 * g + k] << 8) + (uint32_t)al[4 * g + k]) >> 7;
+                split4(t[0], t[1], t[2], t[3], uh[g], ul[g]);
+            }
+            // ================= inverse pass 2 (rows): T^T x intermediate =================
+            ah = mfma(f3, as_v4i(uh), splat16(0));
+            al = mfma(f3, as_v4i(ul), cin_i2);
+            // the prediction in the result's layout: register group g = bytes x = 8 g + 4 h .. + 3 of the lane's row
+            uint32_t pq[4] = {predw[0], predw[1], predw[2], predw[3]};  // dwords 4 h .. 4 h + 3 of the row
+            swap32(pq[0], pq[1]);  // -> pq[0] = dword h, pq[1] = dword 4 + h
+            swap32(pq[2], pq[3]);  // -> pq[2] = dword 2 + h, pq[3] = dword 6 + h
+            const uint32_t pg[4] = {pq[0], pq[2], pq[1], pq[3]};
+            uint32_t rq[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                // (sum + 2048) >> 12, wrap (truncating pack), + pred, Clip (src/pixel.cpp:757-761): the saturating
+                // Int16 add cannot change a sum that is clipped to 0..255 anyway
+                uint32_t t[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) t[k] = (((uint32_t)ah[4 * g + k] << 8) + (uint32_t)al[4 * g + k]) << 4;
+                const v2s r0 = __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, perm(t[1], t[0], 0x07060302u)),
+                                                             __builtin_bit_cast(v2s, perm(0u, pg[g], 0x0c010c00u)));
+                const v2s r1 = __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, perm(t[3], t[2], 0x07060302u)),
+                                                             __builtin_bit_cast(v2s, perm(0u, pg[g], 0x0c030c02u)));
+                rq[g] = perm(sat_pk_u8_i16(__builtin_bit_cast(uint32_t, r1)), sat_pk_u8_i16(__builtin_bit_cast(uint32_t, r0)),
+                             0x05040100u);
+            }
+            // back to "16 consecutive bytes per lane": dwords 4 h .. 4 h + 3
+            uint32_t ro[4] = {rq[0], rq[2], rq[1], rq[3]};  // dword h, 4 + h, 2 + h, 6 + h
+            swap32(ro[0], ro[1]);  // -> dwords 4 h, 4 h + 1
+            swap32(ro[2], ro[3]);  // -> dwords 4 h + 2, 4 h + 3
+            if (row_ok && 16 * h < wvalid) {
+                uint8_t *rp = d.d_rec + (int64_t)f * d.rec_frame_stride + (int64_t)y * d.rec_stride + xh;
+                if (xh + 16 <= d.width) {
+                    P128 a;
+                    a.v[0] = ro[0];
+                    a.v[1] = ro[1];
+                    a.v[2] = ro[2];
+                    a.v[3] = ro[3];
+                    *reinterpret_cast<P128 *>(rp) = a;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+                        if (xh + 4 * i < d.width) reinterpret_cast<P32 *>(rp + 4 * i)->v = ro[i];
+                }
+            }
+        }
+    }
+}
+
+template <int MODE> static void launch_n(int tu, dim3 grid, hipStream_t stream, const TqParams &p)
+{
+    switch (tu) {
+    case 4: hipLaunchKernelGGL((tq_mfma_kernel<4, MODE>), grid, dim3(256), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((tq_mfma_kernel<8, MODE>), grid, dim3(256), 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((tq_mfma_kernel<16, MODE>), grid, dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((tq_mfma_kernel<32, MODE>), grid, dim3(256), 0, stream, p); break;
+    }
+}
+
+// p.ntiles tiles of 32x32; a wave takes `kTilesPerWave` of them (the constant operands are set up once per wave)
+int launch_tq_mfma(int mode, const TqParams &p, hipStream_t stream)
+{
+    constexpr int kTilesPerWave = 4;
+    const int64_t groups = ((int64_t)p.ntiles + 4 * kTilesPerWave - 1) / (4 * kTilesPerWave);
+    const dim3 grid((unsigned)(groups < 1 ? 1 : groups));
+    if (mode == TQ_FWD)
+        launch_n<TQ_FWD>(p.d.tu, grid, stream, p);
+    else if (mode == TQ_INV)
+        launch_n<TQ_INV>(p.d.tu, grid, stream, p);
+    else
+        launch_n<TQ_BOTH>(p.d.tu, grid, stream, p);
+    return hip_status(hipGetLastError());
+}
+
+}  // namespace x265amd
