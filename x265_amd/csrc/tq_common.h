@@ -13,6 +13,7 @@ struct TqParams {
     int q_bits;
     unsigned q_rnd;
     int dq_scale, dq_shift, dq_rnd;
+    int mv_ctu_log2, mv_ctus_x;    // with d.d_mv: log2 of d.mv_ctu, vectors per picture row
 };
 
 enum { TQ_FWD = 1, TQ_INV = 2, TQ_BOTH = 3 };

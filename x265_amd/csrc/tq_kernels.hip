@@ -410,6 +410,16 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
                    d.mv_ctu % d.tu))
         return X265AMD_ERR_ARG;
     if (d.mv_shift < 0 || d.mv_shift > 3) return X265AMD_ERR_ARG;
+    // strides: a row must hold the picture (a zero-initialised stride would make every row alias); outputs of a
+    // batch need their own planes.  With d_mv the prediction plane is addressed relative to d_pred in both
+    // directions (vectors), so only its sign is checked.
+    if (d.level_stride < d.width || d.pred_stride < (d.d_mv ? 1 : d.width)) return X265AMD_ERR_ARG;
+    if ((MODE & TQ_FWD) && d.src_stride < d.width) return X265AMD_ERR_ARG;
+    if ((MODE & TQ_INV) && d.rec_stride < d.width) return X265AMD_ERR_ARG;
+    if (d.nframes > 1 && (d.level_frame_stride == 0 || ((MODE & TQ_INV) && d.rec_frame_stride == 0) ||
+                          (d.d_abs_sum && (MODE & TQ_FWD) && d.abs_sum_frame_stride == 0)))
+        return X265AMD_ERR_ARG;
+    if ((int64_t)d.height * d.level_stride > 0x3fffffff) return X265AMD_ERR_ARG;  // 32-bit byte offsets inside a plane
     if (d.nframes == 0) return X265AMD_OK;
 
     TqParams p;
@@ -420,6 +430,8 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     if (nt > 0x7fffffff) return X265AMD_ERR_ARG;
     p.ntiles = (int)nt;
     quant_constants(d.tu, d.qp, d.slice_type, p);
+    p.mv_ctu_log2 = d.d_mv ? ilog2(d.mv_ctu) : 0;
+    p.mv_ctus_x = d.d_mv ? d.width / d.mv_ctu : 0;
     if (coef_in) {  // the plane already holds xDeQuant's output: (c * 1 + 0) >> 0, and the clip is a no-op on Int16
         p.dq_scale = 1;
         p.dq_rnd = 0;
@@ -466,7 +478,8 @@ extern "C" int x265amd_quant_plane(const int16_t *d_coef, int16_t *d_level, int 
 {
     if (!initialised()) return X265AMD_ERR_NOT_INIT;
     if (!d_coef || !d_level || (tu != 4 && tu != 8 && tu != 16 && tu != 32)) return X265AMD_ERR_ARG;
-    if (width <= 0 || height <= 0 || width % tu || height % tu || qp < 0 || qp > 51) return X265AMD_ERR_ARG;
+    if (width <= 0 || height <= 0 || width % tu || height % tu || qp < 0 || qp > 51 || stride < width) return X265AMD_ERR_ARG;
+    if (slice_type < X265AMD_SLICE_I || slice_type > X265AMD_SLICE_B) return X265AMD_ERR_ARG;
     TqParams p;
     quant_constants(tu, qp, slice_type, p);
     hipLaunchKernelGGL(quant_plane_kernel, dim3((width + 255) / 256, height), dim3(256), 0, (hipStream_t)stream,
@@ -484,7 +497,7 @@ extern "C" int x265amd_dequant_plane(const int16_t *d_level, int16_t *d_coef, in
 {
     if (!initialised()) return X265AMD_ERR_NOT_INIT;
     if (!d_coef || !d_level || (tu != 4 && tu != 8 && tu != 16 && tu != 32)) return X265AMD_ERR_ARG;
-    if (width <= 0 || height <= 0 || width % tu || height % tu || qp < 0 || qp > 51) return X265AMD_ERR_ARG;
+    if (width <= 0 || height <= 0 || width % tu || height % tu || qp < 0 || qp > 51 || stride < width) return X265AMD_ERR_ARG;
     TqParams p;
     quant_constants(tu, qp, X265AMD_SLICE_I, p);
     hipLaunchKernelGGL(dequant_plane_kernel, dim3((width + 255) / 256, height), dim3(256), 0, (hipStream_t)stream,

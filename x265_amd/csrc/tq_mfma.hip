@@ -121,16 +121,27 @@ __device__ __forceinline__ void swap32(uint32_t &x, uint32_t &y)  // x's upper h
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------
-// One wave = one 32x32 tile at a time; a workgroup's four waves take four tiles that are neighbours in x.
+// One wave = one 32x32 tile at a time.  Grid: x = groups of four tile columns (a workgroup's four waves take
+// four tiles that are neighbours in x: 128 contiguous bytes per picture row), y = runs of kRowsPerWave tile
+// rows (the constant operands are set up once per wave and serve the run), z = frame.  Every address is a
+// wave-uniform base plus a 32-bit lane offset.
+constexpr int kRowsPerWave = 4;
+
 template <int N, int MODE>
-__global__ __launch_bounds__(256) void tq_mfma_kernel(const TqParams p)
+__global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
 {
     constexpr int L2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
     constexpr int FI = L2 - 2;
     constexpr int sh1 = L2 - 1, sh2 = L2 + 6;
     const x265amd_tq_desc &d = p.d;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
+    const int tx = blockIdx.x * 4 + wave;
+    if (tx >= p.tiles_x) return;  // wave-uniform; no barriers in this kernel
+    const int f = blockIdx.z;
+    const int x0 = tx * 32;
+    const int wvalid = min(32, d.width - x0);  // a multiple of N
 
     // constant operands of this lane
     const FragSet &F = kFrags[FI];
@@ -155,54 +166,68 @@ __global__ __launch_bounds__(256) void tq_mfma_kernel(const TqParams p)
     // the "+ 1" of pass 1 and the "+ 128" of pass 2's low bytes, both on DC rows only (header comment)
     const int dc_corr = (N == 4 || h == 0) ? ((1 + ((c & (N - 1)) == 0 ? 1 : 0)) << (13 + L2)) : 0;
 
-    const int tpf = p.tiles_x * p.tiles_y;
-    const int tus_x = d.width / N;
-    for (int tile = blockIdx.x * 4 + wave; tile < p.ntiles; tile += gridDim.x * 4) {
-        const int f = tile / tpf;
-        const int trem = tile - f * tpf;
-        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-        const int x0 = tx * 32, y0 = ty * 32;
-        const int wvalid = min(32, d.width - x0), hvalid = min(32, d.height - y0);  // multiples of N
-        const bool full = wvalid == 32 && hvalid == 32;
+    // wave-uniform plane bases; lane offsets are unsigned 32-bit (planes are far below 4 GB)
+    const uint8_t *src_pl = (MODE & TQ_FWD) ? d.d_src + (int64_t)f * d.src_frame_stride : nullptr;
+    const uint8_t *pred_pl = d.d_pred + (int64_t)f * d.pred_frame_stride;
+    uint8_t *rec_pl = (MODE & TQ_INV) ? d.d_rec + (int64_t)f * d.rec_frame_stride : nullptr;
+    // the level / coefficient plane of this frame as a buffer resource: 32-bit lane offset + scalar row offset per
+    // access (no per-lane 64-bit address arithmetic), and anything past the plane's last element is dropped by the hardware
+    int16_t *lvl_pl = d.d_level + (int64_t)f * d.level_frame_stride;
+    int16_t *coef_pl = ((MODE & TQ_FWD) && d.d_coef) ? d.d_coef + (int64_t)f * d.level_frame_stride : nullptr;
+    const uint32_t plane_bytes = (uint32_t)(((int64_t)(d.height - 1) * d.level_stride + d.width) * 2);
+    const __amdgpu_buffer_rsrc_t lvl_rs = __builtin_amdgcn_make_buffer_rsrc(lvl_pl, 0, plane_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t coef_rs = __builtin_amdgcn_make_buffer_rsrc(coef_pl ? coef_pl : lvl_pl, 0, coef_pl ? plane_bytes : 0, 0x00020000);
+    const int row_bytes = d.level_stride * 2;
+    const x265amd_mv *mv_pl = d.d_mv ? d.d_mv + (int64_t)f * d.mv_frame_stride : nullptr;
+    const int tus_x = d.width >> L2;
+    const int xh = x0 + 16 * h;                    // the lane's 16 bytes of a picture row start here
+    const bool half_ok = 16 * h < wvalid;
+    const bool col_ok = c < wvalid;                // lane = column c of the tile in the coefficient layout
+
+    const int ty_end = min((int)(blockIdx.y + 1) * kRowsPerWave, p.tiles_y);
+    for (int ty = blockIdx.y * kRowsPerWave; ty < ty_end; ty++) {
+        const int y0 = ty * 32;
+        const int hvalid = min(32, d.height - y0);  // a multiple of N
+        const bool full = wvalid == 32 && hvalid == 32;  // wave-uniform
+        const int y = y0 + c;                       // lane = row c of the tile in the row layout
+        const bool row_ok = c < hvalid && half_ok;
 
         // ---- the lane's 16 bytes of its picture row: prediction (kept for the reconstruction) and source ----
-        const bool row_ok = c < hvalid;           // lane = row c of the tile, bytes 16 h .. 16 h + 15
-        const int xh = x0 + 16 * h, y = y0 + c;
         uint32_t predw[4] = {0u, 0u, 0u, 0u};
-        if (row_ok && 16 * h < wvalid) {
-            const uint8_t *pp = d.d_pred + (int64_t)f * d.pred_frame_stride;
-            const uint8_t *q;
-            if (d.d_mv) {  // integer-pel motion compensation fused into the load; mv_ctu >= 16: one vector per half row
-                const x265amd_mv m = d.d_mv[(int64_t)f * d.mv_frame_stride + (y / d.mv_ctu) * (d.width / d.mv_ctu) + xh / d.mv_ctu];
-                q = pp + (int64_t)(y + (m.mvy >> d.mv_shift)) * d.pred_stride + xh + (m.mvx >> d.mv_shift);
-            } else {
-                q = pp + (int64_t)y * d.pred_stride + xh;
+        {
+            // SIGNED offset: with vectors the prediction may lie above / left of d_pred (a window into a larger plane)
+            int64_t off = (int64_t)((uint32_t)y * (uint32_t)d.pred_stride + (uint32_t)xh);
+            if (mv_pl) {  // integer-pel motion compensation fused into the load; mv_ctu >= 16: one vector per half row
+                x265amd_mv m = {0, 0, 0};
+                if (row_ok) m = mv_pl[(uint32_t)((y >> p.mv_ctu_log2) * p.mv_ctus_x + (xh >> p.mv_ctu_log2))];
+                off = (int64_t)(y + (m.mvy >> d.mv_shift)) * d.pred_stride + (xh + (m.mvx >> d.mv_shift));
             }
-            if (xh + 16 <= d.width) {
-                const P128 a = *reinterpret_cast<const P128 *>(q);
+            if (full || (row_ok && xh + 16 <= d.width)) {
+                const P128 a = *reinterpret_cast<const P128 *>(pred_pl + off);
 #pragma unroll
                 for (int i = 0; i < 4; i++) predw[i] = a.v[i];
-            } else {
+            } else if (row_ok) {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if (xh + 4 * i < d.width) predw[i] = reinterpret_cast<const P32 *>(q + 4 * i)->v;
+                    if (xh + 4 * i < d.width) predw[i] = reinterpret_cast<const P32 *>(pred_pl + off + 4 * i)->v;
             }
         }
 
         int level[16];  // the lane's column of quantised levels: x = x0 + c, y = y0 + rho(r, h)
-        const bool col_ok = c < wvalid;
+        // element offset of the lane's (column c, row 4 h) in the level / coefficient planes; register r adds rho(r, 0) rows
+        const int lv_off = (int)(((uint32_t)(y0 + 4 * h) * (uint32_t)d.level_stride + (uint32_t)(x0 + c)) * 2u);  // bytes
         if constexpr (MODE & TQ_FWD) {
             uint32_t srcw[4] = {0u, 0u, 0u, 0u};
-            if (row_ok && 16 * h < wvalid) {
-                const uint8_t *q = d.d_src + (int64_t)f * d.src_frame_stride + (int64_t)y * d.src_stride + xh;
-                if (xh + 16 <= d.width) {
-                    const P128 a = *reinterpret_cast<const P128 *>(q);
+            {
+                const uint32_t off = (uint32_t)y * (uint32_t)d.src_stride + (uint32_t)xh;
+                if (full || (row_ok && xh + 16 <= d.width)) {
+                    const P128 a = *reinterpret_cast<const P128 *>(src_pl + off);
 #pragma unroll
                     for (int i = 0; i < 4; i++) srcw[i] = a.v[i];
-                } else {
+                } else if (row_ok) {
 #pragma unroll
                     for (int i = 0; i < 4; i++)
-                        if (xh + 4 * i < d.width) srcw[i] = reinterpret_cast<const P32 *>(q + 4 * i)->v;
+                        if (xh + 4 * i < d.width) srcw[i] = reinterpret_cast<const P32 *>(src_pl + off + 4 * i)->v;
                 }
             }
             // ================= pass 1: residual x T^T (rows of the tile) =================
@@ -228,65 +253,65 @@ __global__ __launch_bounds__(256) void tq_mfma_kernel(const TqParams p)
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 if ((rho(r, 0) & (N - 1)) == 0) al[r] += dc_corr;  // rho(r, 1) = rho(r, 0) + 4: a DC row too iff N == 4
-            int16_t *lvp = d.d_level + (int64_t)f * d.level_frame_stride + (int64_t)y0 * d.level_stride + x0 + c;
-            int16_t *cfp = d.d_coef ? d.d_coef + (int64_t)f * d.level_frame_stride + (int64_t)y0 * d.level_stride + x0 + c : nullptr;
             uint32_t psum[4] = {0u, 0u, 0u, 0u};
+            int cf[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int t = (int)(((uint32_t)ah[r] << 8) + (uint32_t)al[r]);
                 if constexpr (N == 4) t += rnd2;
-                const int cf = __builtin_amdgcn_sbfe(t, sh2, 16);  // truncating Int16 store of the coefficient
+                cf[r] = __builtin_amdgcn_sbfe(t, sh2, 16);  // truncating Int16 store of the coefficient
                 // xQuant
-                const int q = mul24(cf, (int)p.q_scale) + (cf < 0 ? q_neg : q_pos);
+                const int q = mul24(cf[r], (int)p.q_scale) + (cf[r] < 0 ? q_neg : q_pos);
                 const uint32_t lb = (uint32_t)q >> p.q_bits;   // level + q_bias
                 psum[r >> 2] = sad_u32(lb, q_bias, psum[r >> 2]);
                 level[r] = (int)(lb - q_bias);
-                const int yy = rho(r, h);
-                if (full || (col_ok && yy < hvalid)) {
-                    lvp[(int64_t)yy * d.level_stride] = (int16_t)level[r];
-                    if (cfp) cfp[(int64_t)yy * d.level_stride] = (int16_t)cf;
-                }
+            }
+            if (full) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    __builtin_amdgcn_raw_buffer_store_b16((short)level[r], lvl_rs, lv_off, rho(r, 0) * row_bytes, 0);
+            } else if (col_ok) {
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (rho(r, h) < hvalid) __builtin_amdgcn_raw_buffer_store_b16((short)level[r], lvl_rs, lv_off, rho(r, 0) * row_bytes, 0);
+            }
+            if (coef_pl && col_ok) {  // stage-by-stage checks only
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    if (rho(r, h) < hvalid) __builtin_amdgcn_raw_buffer_store_b16((short)cf[r], coef_rs, lv_off, rho(r, 0) * row_bytes, 0);
             }
             if (d.d_abs_sum) {
                 // xQuant's return value per TU: registers 4q .. 4q+3 are rows 8q + 4h .. + 3
                 uint32_t s[4];
-                int ns;
+                constexpr int ns = N == 32 ? 1 : N == 16 ? 2 : 4;
                 if constexpr (N == 32) {
                     s[0] = psum[0] + psum[1] + psum[2] + psum[3];
-                    ns = 1;
                 } else if constexpr (N == 16) {
                     s[0] = psum[0] + psum[1];
                     s[1] = psum[2] + psum[3];
-                    ns = 2;
                 } else {
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4++) s[q4] = psum[q4];
-                    ns = 4;
                 }
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    if (i >= ns) break;
+                for (int i = 0; i < ns; i++) {
 #pragma unroll
                     for (int o = 1; o < N && o < 32; o <<= 1) s[i] += __shfl_xor(s[i], o);
                     if constexpr (N >= 8) s[i] += __shfl_xor(s[i], 32);
                 }
                 if ((c & (N - 1)) == 0 && (N == 4 || h == 0) && col_ok) {
-                    uint32_t *ap = d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride + (int64_t)(y0 / N) * tus_x + (x0 + c) / N;
+                    uint32_t *ap = d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride + (int64_t)(y0 >> L2) * tus_x + ((x0 + c) >> L2);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        if (i >= ns) break;
+                    for (int i = 0; i < ns; i++) {
                         const int tuy = N == 4 ? 2 * i + h : i;  // TU row inside the tile
                         if (tuy * N < hvalid) ap[(int64_t)tuy * tus_x] = s[i];
                     }
                 }
             }
         } else {
-            const int16_t *lvp = d.d_level + (int64_t)f * d.level_frame_stride + (int64_t)y0 * d.level_stride + x0 + c;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int yy = rho(r, h);
-                level[r] = (full || (col_ok && yy < hvalid)) ? (int)lvp[(int64_t)yy * d.level_stride] : 0;
-            }
+            for (int r = 0; r < 16; r++)
+                level[r] = (full || (col_ok && rho(r, h) < hvalid)) ? (int)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(lvl_rs, lv_off, rho(r, 0) * row_bytes, 0) : 0;
         }
 
         if constexpr (MODE & TQ_INV) {
@@ -341,20 +366,18 @@ __global__ __launch_bounds__(256) void tq_mfma_kernel(const TqParams p)
             uint32_t ro[4] = {rq[0], rq[2], rq[1], rq[3]};  // dword h, 4 + h, 2 + h, 6 + h
             swap32(ro[0], ro[1]);  // -> dwords 4 h, 4 h + 1
             swap32(ro[2], ro[3]);  // -> dwords 4 h + 2, 4 h + 3
-            if (row_ok && 16 * h < wvalid) {
-                uint8_t *rp = d.d_rec + (int64_t)f * d.rec_frame_stride + (int64_t)y * d.rec_stride + xh;
-                if (xh + 16 <= d.width) {
-                    P128 a;
-                    a.v[0] = ro[0];
-                    a.v[1] = ro[1];
-                    a.v[2] = ro[2];
-                    a.v[3] = ro[3];
-                    *reinterpret_cast<P128 *>(rp) = a;
-                } else {
+            const uint32_t off = (uint32_t)y * (uint32_t)d.rec_stride + (uint32_t)xh;
+            if (full || (row_ok && xh + 16 <= d.width)) {
+                P128 a;
+                a.v[0] = ro[0];
+                a.v[1] = ro[1];
+                a.v[2] = ro[2];
+                a.v[3] = ro[3];
+                *reinterpret_cast<P128 *>(rec_pl + off) = a;
+            } else if (row_ok) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (xh + 4 * i < d.width) reinterpret_cast<P32 *>(rp + 4 * i)->v = ro[i];
-                }
+                for (int i = 0; i < 4; i++)
+                    if (xh + 4 * i < d.width) reinterpret_cast<P32 *>(rec_pl + off + 4 * i)->v = ro[i];
             }
         }
     }
@@ -370,12 +393,10 @@ template <int MODE> static void launch_n(int tu, dim3 grid, hipStream_t stream, 
     }
 }
 
-// p.ntiles tiles of 32x32; a wave takes `kTilesPerWave` of them (the constant operands are set up once per wave)
 int launch_tq_mfma(int mode, const TqParams &p, hipStream_t stream)
 {
-    constexpr int kTilesPerWave = 4;
-    const int64_t groups = ((int64_t)p.ntiles + 4 * kTilesPerWave - 1) / (4 * kTilesPerWave);
-    const dim3 grid((unsigned)(groups < 1 ? 1 : groups));
+    if (p.d.nframes > 65535) return X265AMD_ERR_ARG;  // grid.z
+    const dim3 grid((unsigned)((p.tiles_x + 3) / 4), (unsigned)((p.tiles_y + kRowsPerWave - 1) / kRowsPerWave), (unsigned)p.d.nframes);
     if (mode == TQ_FWD)
         launch_n<TQ_FWD>(p.d.tu, grid, stream, p);
     else if (mode == TQ_INV)
