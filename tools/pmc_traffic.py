@@ -47,7 +47,7 @@ def main():
             "write_bytes": write.get(k, 0.0) * 1024 / max(nw.get(k, 0), 1),
         }
     me = [k for k in kernels if k.startswith(("sea_", "box16", "me_fullsearch"))]
-    tq = [k for k in kernels if k.startswith("tq_kernel")]
+    tq = [k for k in kernels if k.startswith(("tq_kernel", "tq_mfma"))]
     entry = {
         "launches": launches,
         "kernels": kernels,

@@ -419,7 +419,9 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     if (d.nframes > 1 && (d.level_frame_stride == 0 || ((MODE & TQ_INV) && d.rec_frame_stride == 0) ||
                           (d.d_abs_sum && (MODE & TQ_FWD) && d.abs_sum_frame_stride == 0)))
         return X265AMD_ERR_ARG;
-    if ((int64_t)d.height * d.level_stride > 0x3fffffff) return X265AMD_ERR_ARG;  // 32-bit byte offsets inside a plane
+    if ((int64_t)d.height * d.level_stride > 0x1fffffff || (int64_t)d.height * d.src_stride > 0x3fffffff ||
+        (int64_t)d.height * d.rec_stride > 0x3fffffff || (int64_t)d.height * d.pred_stride > 0x3fffffff)
+        return X265AMD_ERR_ARG;  // 32-bit byte offsets inside a plane, all below the out-of-range sentinel of tq_mfma.hip
     if (d.nframes == 0) return X265AMD_OK;
 
     TqParams p;

@@ -77,12 +77,6 @@ constexpr FragSet make_frags(int n)
 __device__ const FragSet kFrags[4] = {make_frags(4), make_frags(8), make_frags(16), make_frags(32)};
 
 // ---- small helpers ---------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(1))) P128 {
-    uint32_t v[4];
-};
-struct __attribute__((packed, aligned(1))) P32 {
-    uint32_t v;
-};
 __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 __device__ __forceinline__ v4i as_v4i(const uint32_t (&w)[4]) { return v4i{(int)w[0], (int)w[1], (int)w[2], (int)w[3]}; }
 __device__ __forceinline__ v16i splat16(int v) { return v16i{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v}; }
@@ -166,70 +160,122 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     // the "+ 1" of pass 1 and the "+ 128" of pass 2's low bytes, both on DC rows only (header comment)
     const int dc_corr = (N == 4 || h == 0) ? ((1 + ((c & (N - 1)) == 0 ? 1 : 0)) << (13 + L2)) : 0;
 
-    // wave-uniform plane bases; lane offsets are unsigned 32-bit (planes are far below 4 GB)
-    const uint8_t *src_pl = (MODE & TQ_FWD) ? d.d_src + (int64_t)f * d.src_frame_stride : nullptr;
+    // ---- memory: straight-line, branch-free accesses ----
+    // Every access is a buffer instruction.  Planes whose extent the descriptor gives (source, reconstruction,
+    // levels, coefficients) are resources of exactly that extent: a lane that has nothing to load or store is
+    // given an offset past the end, which the hardware answers with zeros / drops -- no divergent control flow
+    // around the accesses, and no access of this kernel to those planes can leave them.  The prediction may be
+    // a window into a larger plane reached through vectors (offsets below d_pred included), so its resource
+    // starts 2^30 bytes BELOW the window and has no end; lanes with nothing to read get the window's first bytes.
+    constexpr uint32_t kOob = 0x7ffffff0u;  // beyond any plane (launch_tq caps a plane at 2^30 bytes)
+    constexpr uint32_t kPredBias = 1u << 30;
     const uint8_t *pred_pl = d.d_pred + (int64_t)f * d.pred_frame_stride;
-    uint8_t *rec_pl = (MODE & TQ_INV) ? d.d_rec + (int64_t)f * d.rec_frame_stride : nullptr;
-    // the level / coefficient plane of this frame as a buffer resource: 32-bit lane offset + scalar row offset per
-    // access (no per-lane 64-bit address arithmetic), and anything past the plane's last element is dropped by the hardware
+    const __amdgpu_buffer_rsrc_t pred_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(pred_pl) - kPredBias), 0, 0xffffffffu, 0x00020000);
     int16_t *lvl_pl = d.d_level + (int64_t)f * d.level_frame_stride;
-    int16_t *coef_pl = ((MODE & TQ_FWD) && d.d_coef) ? d.d_coef + (int64_t)f * d.level_frame_stride : nullptr;
-    const uint32_t plane_bytes = (uint32_t)(((int64_t)(d.height - 1) * d.level_stride + d.width) * 2);
-    const __amdgpu_buffer_rsrc_t lvl_rs = __builtin_amdgcn_make_buffer_rsrc(lvl_pl, 0, plane_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t coef_rs = __builtin_amdgcn_make_buffer_rsrc(coef_pl ? coef_pl : lvl_pl, 0, coef_pl ? plane_bytes : 0, 0x00020000);
+    const uint32_t lvl_bytes = (uint32_t)(((int64_t)(d.height - 1) * d.level_stride + d.width) * 2);
+    const __amdgpu_buffer_rsrc_t lvl_rs = __builtin_amdgcn_make_buffer_rsrc(lvl_pl, 0, lvl_bytes, 0x00020000);
+    const bool want_coef = (MODE & TQ_FWD) && d.d_coef;
+    const __amdgpu_buffer_rsrc_t coef_rs = __builtin_amdgcn_make_buffer_rsrc(
+        want_coef ? d.d_coef + (int64_t)f * d.level_frame_stride : lvl_pl, 0, want_coef ? lvl_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (MODE & TQ_FWD) ? const_cast<uint8_t *>(d.d_src) + (int64_t)f * d.src_frame_stride : const_cast<uint8_t *>(pred_pl), 0,
+        (MODE & TQ_FWD) ? (uint32_t)((int64_t)(d.height - 1) * d.src_stride + d.width) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rec_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (MODE & TQ_INV) ? d.d_rec + (int64_t)f * d.rec_frame_stride : const_cast<uint8_t *>(pred_pl), 0,
+        (MODE & TQ_INV) ? (uint32_t)((int64_t)(d.height - 1) * d.rec_stride + d.width) : 0u, 0x00020000);
+    const bool want_sum = (MODE & TQ_FWD) && d.d_abs_sum;
+    const __amdgpu_buffer_rsrc_t sum_rs = __builtin_amdgcn_make_buffer_rsrc(
+        want_sum ? d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride : reinterpret_cast<uint32_t *>(lvl_pl), 0,
+        want_sum ? (uint32_t)((d.height >> L2) * (d.width >> L2)) * 4u : 0u, 0x00020000);
     const int row_bytes = d.level_stride * 2;
     const x265amd_mv *mv_pl = d.d_mv ? d.d_mv + (int64_t)f * d.mv_frame_stride : nullptr;
     const int tus_x = d.width >> L2;
     const int xh = x0 + 16 * h;                    // the lane's 16 bytes of a picture row start here
     const bool half_ok = 16 * h < wvalid;
     const bool col_ok = c < wvalid;                // lane = column c of the tile in the coefficient layout
+    const bool wide = (wvalid & 15) == 0;          // wave-uniform: the row halves are whole 16-byte pieces
 
-    const int ty_end = min((int)(blockIdx.y + 1) * kRowsPerWave, p.tiles_y);
-    for (int ty = blockIdx.y * kRowsPerWave; ty < ty_end; ty++) {
+    const int ty_beg = blockIdx.y * kRowsPerWave;
+    const int ty_end = min(ty_beg + kRowsPerWave, p.tiles_y);
+
+    // the vectors of every tile of the run, fetched up front (only mvx | mvy: the first dword of x265amd_mv): the
+    // prediction loads that depend on them can then be issued a whole tile ahead
+    const __amdgpu_buffer_rsrc_t mv_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<x265amd_mv *>(mv_pl ? mv_pl : reinterpret_cast<const x265amd_mv *>(pred_pl)), 0,
+        mv_pl ? (uint32_t)(p.mv_ctus_x * (d.height >> p.mv_ctu_log2)) * 8u : 0u, 0x00020000);
+    uint32_t mvw[kRowsPerWave];
+#pragma unroll
+    for (int k = 0; k < kRowsPerWave; k++) mvw[k] = 0u;
+    if (mv_pl) {  // wave-uniform
+#pragma unroll
+        for (int k = 0; k < kRowsPerWave; k++) {
+            const int yk = (ty_beg + k) * 32 + c;
+            const bool ok = ty_beg + k < ty_end && yk < d.height && half_ok;
+            const uint32_t idx = ok ? (uint32_t)((yk >> p.mv_ctu_log2) * p.mv_ctus_x + (xh >> p.mv_ctu_log2)) : 0u;
+            mvw[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mv_rs, (int)(idx * 8u), 0, 0);  // entry 0 exists: the picture has a block
+        }
+    }
+
+    // the lane's 16 bytes of its picture row (lane = row c of the tile, bytes 16 h .. 16 h + 15) of tile row `ty`
+    auto load_rows = [&](int ty, bool active, uint32_t mv, uint32_t (&sw)[4], uint32_t (&pw)[4]) {
+        const int y = ty * 32 + c;
+        const bool row_ok = active && y < d.height && half_ok;
+        // offset from the biased base, modulo 2^32: with vectors the prediction may lie above / left of d_pred, and
+        // the wrap-around of unsigned arithmetic gives exactly the low 32 bits of the signed offset
+        uint32_t poff = (uint32_t)y * (uint32_t)d.pred_stride + (uint32_t)xh;
+        if (mv_pl) {  // wave-uniform; integer-pel motion compensation fused into the load (mv_ctu >= 16: one vector per half row)
+            const int mvx = (int)(int16_t)(mv & 0xffffu), mvy = (int)mv >> 16;
+            poff = (uint32_t)(y + (mvy >> d.mv_shift)) * (uint32_t)d.pred_stride + (uint32_t)(xh + (mvx >> d.mv_shift));
+        }
+        const uint32_t pofs = kPredBias + poff;
+        const uint32_t soff = (uint32_t)y * (uint32_t)d.src_stride + (uint32_t)xh;
+        if (wide) {  // wave-uniform
+            const v4i a = __builtin_amdgcn_raw_buffer_load_b128(pred_rs, (int)(row_ok ? pofs : kPredBias), 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) pw[i] = row_ok ? (uint32_t)a[i] : 0u;
+            if constexpr (MODE & TQ_FWD) {
+                const v4i b = __builtin_amdgcn_raw_buffer_load_b128(src_rs, (int)(row_ok ? soff : kOob), 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) sw[i] = (uint32_t)b[i];
+            }
+        } else {  // widths that are not a multiple of 16: dword by dword
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool ok = row_ok && xh + 4 * i < d.width;
+                const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pred_rs, (int)(ok ? pofs + 4 * i : kPredBias), 0, 0);
+                pw[i] = ok ? v : 0u;
+                if constexpr (MODE & TQ_FWD)
+                    sw[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(ok ? soff + 4 * i : kOob), 0, 0);
+                else
+                    sw[i] = 0u;
+            }
+        }
+        if constexpr (!(MODE & TQ_FWD)) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) sw[i] = 0u;
+        }
+    };
+
+    uint32_t srcw[4], predw[4], src_nx[4], pred_nx[4];
+    load_rows(ty_beg, true, mvw[0], srcw, predw);
+#pragma unroll
+    for (int k = 0; k < kRowsPerWave; k++) {
+        const int ty = ty_beg + k;
+        if (ty >= ty_end) break;  // wave-uniform
+        // the next tile's rows are on their way while this one is transformed (past the run's end: all lanes idle)
+        if (k + 1 < kRowsPerWave) load_rows(ty + 1, ty + 1 < ty_end, mvw[k + 1 < kRowsPerWave ? k + 1 : 0], src_nx, pred_nx);
         const int y0 = ty * 32;
         const int hvalid = min(32, d.height - y0);  // a multiple of N
-        const bool full = wvalid == 32 && hvalid == 32;  // wave-uniform
         const int y = y0 + c;                       // lane = row c of the tile in the row layout
         const bool row_ok = c < hvalid && half_ok;
 
-        // ---- the lane's 16 bytes of its picture row: prediction (kept for the reconstruction) and source ----
-        uint32_t predw[4] = {0u, 0u, 0u, 0u};
-        {
-            // SIGNED offset: with vectors the prediction may lie above / left of d_pred (a window into a larger plane)
-            int64_t off = (int64_t)((uint32_t)y * (uint32_t)d.pred_stride + (uint32_t)xh);
-            if (mv_pl) {  // integer-pel motion compensation fused into the load; mv_ctu >= 16: one vector per half row
-                x265amd_mv m = {0, 0, 0};
-                if (row_ok) m = mv_pl[(uint32_t)((y >> p.mv_ctu_log2) * p.mv_ctus_x + (xh >> p.mv_ctu_log2))];
-                off = (int64_t)(y + (m.mvy >> d.mv_shift)) * d.pred_stride + (xh + (m.mvx >> d.mv_shift));
-            }
-            if (full || (row_ok && xh + 16 <= d.width)) {
-                const P128 a = *reinterpret_cast<const P128 *>(pred_pl + off);
-#pragma unroll
-                for (int i = 0; i < 4; i++) predw[i] = a.v[i];
-            } else if (row_ok) {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    if (xh + 4 * i < d.width) predw[i] = reinterpret_cast<const P32 *>(pred_pl + off + 4 * i)->v;
-            }
-        }
-
         int level[16];  // the lane's column of quantised levels: x = x0 + c, y = y0 + rho(r, h)
-        // element offset of the lane's (column c, row 4 h) in the level / coefficient planes; register r adds rho(r, 0) rows
-        const int lv_off = (int)(((uint32_t)(y0 + 4 * h) * (uint32_t)d.level_stride + (uint32_t)(x0 + c)) * 2u);  // bytes
+        // byte offset of the lane's (column c, row 4 h) in the level / coefficient planes; register r adds rho(r, 0)
+        // rows through the scalar offset.  Lanes outside the plane's width are sent past the end; rows past its
+        // height ARE past the end of the resource.
+        const int lv_off = col_ok ? (int)(((uint32_t)(y0 + 4 * h) * (uint32_t)d.level_stride + (uint32_t)(x0 + c)) * 2u) : (int)kOob;
         if constexpr (MODE & TQ_FWD) {
-            uint32_t srcw[4] = {0u, 0u, 0u, 0u};
-            {
-                const uint32_t off = (uint32_t)y * (uint32_t)d.src_stride + (uint32_t)xh;
-                if (full || (row_ok && xh + 16 <= d.width)) {
-                    const P128 a = *reinterpret_cast<const P128 *>(src_pl + off);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) srcw[i] = a.v[i];
-                } else if (row_ok) {
-#pragma unroll
-                    for (int i = 0; i < 4; i++)
-                        if (xh + 4 * i < d.width) srcw[i] = reinterpret_cast<const P32 *>(src_pl + off + 4 * i)->v;
-                }
-            }
             // ================= pass 1: residual x T^T (rows of the tile) =================
             uint32_t sa[4], pa[4];
 #pragma unroll
@@ -266,21 +312,15 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
                 psum[r >> 2] = sad_u32(lb, q_bias, psum[r >> 2]);
                 level[r] = (int)(lb - q_bias);
             }
-            if (full) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                __builtin_amdgcn_raw_buffer_store_b16((short)level[r], lvl_rs, lv_off, rho(r, 0) * row_bytes, 0);
+            if (want_coef) {  // wave-uniform; stage-by-stage checks only
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    __builtin_amdgcn_raw_buffer_store_b16((short)level[r], lvl_rs, lv_off, rho(r, 0) * row_bytes, 0);
-            } else if (col_ok) {
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if (rho(r, h) < hvalid) __builtin_amdgcn_raw_buffer_store_b16((short)level[r], lvl_rs, lv_off, rho(r, 0) * row_bytes, 0);
+                    __builtin_amdgcn_raw_buffer_store_b16((short)cf[r], coef_rs, lv_off, rho(r, 0) * row_bytes, 0);
             }
-            if (coef_pl && col_ok) {  // stage-by-stage checks only
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    if (rho(r, h) < hvalid) __builtin_amdgcn_raw_buffer_store_b16((short)cf[r], coef_rs, lv_off, rho(r, 0) * row_bytes, 0);
-            }
-            if (d.d_abs_sum) {
+            if (want_sum) {  // wave-uniform
                 // xQuant's return value per TU: registers 4q .. 4q+3 are rows 8q + 4h .. + 3
                 uint32_t s[4];
                 constexpr int ns = N == 32 ? 1 : N == 16 ? 2 : 4;
@@ -299,19 +339,19 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
                     for (int o = 1; o < N && o < 32; o <<= 1) s[i] += __shfl_xor(s[i], o);
                     if constexpr (N >= 8) s[i] += __shfl_xor(s[i], 32);
                 }
-                if ((c & (N - 1)) == 0 && (N == 4 || h == 0) && col_ok) {
-                    uint32_t *ap = d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride + (int64_t)(y0 >> L2) * tus_x + ((x0 + c) >> L2);
+                // one lane per TU column writes; TU rows below the picture are past the end of the resource
+                const bool writer = (c & (N - 1)) == 0 && (N == 4 || h == 0) && col_ok;
+                const uint32_t a_off = writer ? (uint32_t)((y0 >> L2) * tus_x + ((x0 + c) >> L2)) * 4u : kOob;
 #pragma unroll
-                    for (int i = 0; i < ns; i++) {
-                        const int tuy = N == 4 ? 2 * i + h : i;  // TU row inside the tile
-                        if (tuy * N < hvalid) ap[(int64_t)tuy * tus_x] = s[i];
-                    }
+                for (int i = 0; i < ns; i++) {
+                    const int tuy = N == 4 ? 2 * i + h : i;  // TU row inside the tile
+                    __builtin_amdgcn_raw_buffer_store_b32((int)s[i], sum_rs, (int)(a_off + (uint32_t)(tuy * tus_x) * 4u), 0, 0);
                 }
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                level[r] = (full || (col_ok && rho(r, h) < hvalid)) ? (int)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(lvl_rs, lv_off, rho(r, 0) * row_bytes, 0) : 0;
+            for (int r = 0; r < 16; r++)  // out of the plane: zeros
+                level[r] = (int)(int16_t)__builtin_amdgcn_raw_buffer_load_b16(lvl_rs, lv_off, rho(r, 0) * row_bytes, 0);
         }
 
         if constexpr (MODE & TQ_INV) {
@@ -367,18 +407,19 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
             swap32(ro[0], ro[1]);  // -> dwords 4 h, 4 h + 1
             swap32(ro[2], ro[3]);  // -> dwords 4 h + 2, 4 h + 3
             const uint32_t off = (uint32_t)y * (uint32_t)d.rec_stride + (uint32_t)xh;
-            if (full || (row_ok && xh + 16 <= d.width)) {
-                P128 a;
-                a.v[0] = ro[0];
-                a.v[1] = ro[1];
-                a.v[2] = ro[2];
-                a.v[3] = ro[3];
-                *reinterpret_cast<P128 *>(rec_pl + off) = a;
-            } else if (row_ok) {
+            if (wide) {  // wave-uniform
+                __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)ro[0], (int)ro[1], (int)ro[2], (int)ro[3]}, rec_rs,
+                                                      (int)(row_ok ? off : kOob), 0, 0);
+            } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    if (xh + 4 * i < d.width) reinterpret_cast<P32 *>(rec_pl + off + 4 * i)->v = ro[i];
+                    __builtin_amdgcn_raw_buffer_store_b32((int)ro[i], rec_rs, (int)(row_ok && xh + 4 * i < d.width ? off + 4 * i : kOob), 0, 0);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            srcw[i] = src_nx[i];
+            predw[i] = pred_nx[i];
         }
     }
 }
