@@ -18,7 +18,7 @@ struct TqParams {
 
 enum { TQ_FWD = 1, TQ_INV = 2, TQ_BOTH = 3 };
 
-// tq_mfma.hip: all TU sizes; the 4x4 DST (per-TU intra modes) stays with the butterfly kernel
+// tq_mfma.hip: all TU sizes, widths that are multiples of 16; the 4x4 DST (per-TU intra modes) stays with the butterfly kernel
 int launch_tq_mfma(int mode, const TqParams &p, hipStream_t stream);
 
 }  // namespace x265amd

@@ -440,8 +440,9 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
         p.dq_shift = 0;
     }
     // the matrix-core formulation (tq_mfma.hip) wherever the transform matrix is the same for every TU of the
-    // plane; per-TU DST selection at 4x4 (d_modes) and the debug switch keep the butterfly kernel
-    if (g_tq_path != 1 && !(d.tu == 4 && d.d_modes)) return launch_tq_mfma(MODE, p, stream);
+    // plane and the rows split into 16-byte pieces; per-TU DST selection at 4x4 (d_modes), widths that are not a
+    // multiple of 16 and the debug switch keep the butterfly kernel
+    if (g_tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0) return launch_tq_mfma(MODE, p, stream);
     const dim3 grid((unsigned)((nt + 7) / 8)), block(256);
     switch (d.tu) {
     case 4: hipLaunchKernelGGL((tq_kernel<4, MODE>), grid, block, 0, stream, p); break;

@@ -115,13 +115,17 @@ __device__ __forceinline__ void swap32(uint32_t &x, uint32_t &y)  // x's upper h
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------
-// One wave = one 32x32 tile at a time.  Grid: x = groups of four tile columns (a workgroup's four waves take
-// four tiles that are neighbours in x: 128 contiguous bytes per picture row), y = runs of kRowsPerWave tile
-// rows (the constant operands are set up once per wave and serve the run), z = frame.  Every address is a
-// wave-uniform base plus a 32-bit lane offset.
-constexpr int kRowsPerWave = 4;
+// One wave = one 32x32 tile at a time; a workgroup's four waves take four tiles that are neighbours in x (128
+// contiguous bytes per picture row): a UNIT.  Units are numbered frame-major, then tile row, then along x; the
+// grid is sized to what the chip holds at once and every workgroup walks a contiguous, equal share of the
+// units (the work per tile is the same everywhere, so an even split is a balanced one and there is no partial
+// last round of workgroups).  While a unit is transformed, the next unit's rows are in flight, and the vectors
+// of the one after that.
+struct TilePos {  // wave-uniform
+    int f, ty, txg;
+};
 
-template <int N, int MODE>
+template <int N, int MODE, bool MV>
 __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
 {
     constexpr int L2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
@@ -131,11 +135,12 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
-    const int tx = blockIdx.x * 4 + wave;
-    if (tx >= p.tiles_x) return;  // wave-uniform; no barriers in this kernel
-    const int f = blockIdx.z;
-    const int x0 = tx * 32;
-    const int wvalid = min(32, d.width - x0);  // a multiple of N
+
+    const int ntxg = (p.tiles_x + 3) >> 2;
+    const int nunits = ntxg * p.tiles_y * d.nframes;
+    const int per = (nunits + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int u_beg = blockIdx.x * per, u_end = min(u_beg + per, nunits);
+    if (u_beg >= u_end) return;  // block-uniform; no barriers in this kernel
 
     // constant operands of this lane
     const FragSet &F = kFrags[FI];
@@ -160,96 +165,97 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     // the "+ 1" of pass 1 and the "+ 128" of pass 2's low bytes, both on DC rows only (header comment)
     const int dc_corr = (N == 4 || h == 0) ? ((1 + ((c & (N - 1)) == 0 ? 1 : 0)) << (13 + L2)) : 0;
 
-    // ---- memory: straight-line, branch-free accesses ----
-    // Every access is a buffer instruction.  Planes whose extent the descriptor gives (source, reconstruction,
-    // levels, coefficients) are resources of exactly that extent: a lane that has nothing to load or store is
-    // given an offset past the end, which the hardware answers with zeros / drops -- no divergent control flow
-    // around the accesses, and no access of this kernel to those planes can leave them.  The prediction may be
-    // a window into a larger plane reached through vectors (offsets below d_pred included), so its resource
-    // starts 2^30 bytes BELOW the window and has no end; lanes with nothing to read get the window's first bytes.
+    // ---- memory: every access is a buffer instruction ----
+    // Planes whose extent the descriptor gives (source, reconstruction, levels, coefficients, sums, vectors) are
+    // resources of exactly that extent: a lane that has nothing to load or store is given an offset past the
+    // end, which the hardware answers with zeros / drops -- no divergent control flow around the accesses, and
+    // no access of this kernel to those planes can leave them.  The prediction may be a window into a larger
+    // plane reached through vectors (offsets below d_pred included), so its resource starts 2^30 bytes BELOW
+    // the window and has no end; lanes with nothing to read get the window's first bytes.
     constexpr uint32_t kOob = 0x7ffffff0u;  // beyond any plane (launch_tq caps a plane at 2^30 bytes)
     constexpr uint32_t kPredBias = 1u << 30;
-    const uint8_t *pred_pl = d.d_pred + (int64_t)f * d.pred_frame_stride;
-    const __amdgpu_buffer_rsrc_t pred_rs = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(pred_pl) - kPredBias), 0, 0xffffffffu, 0x00020000);
-    int16_t *lvl_pl = d.d_level + (int64_t)f * d.level_frame_stride;
+    constexpr int kRsrcFlags = 0x00020000;
     const uint32_t lvl_bytes = (uint32_t)(((int64_t)(d.height - 1) * d.level_stride + d.width) * 2);
-    const __amdgpu_buffer_rsrc_t lvl_rs = __builtin_amdgcn_make_buffer_rsrc(lvl_pl, 0, lvl_bytes, 0x00020000);
     const bool want_coef = (MODE & TQ_FWD) && d.d_coef;
-    const __amdgpu_buffer_rsrc_t coef_rs = __builtin_amdgcn_make_buffer_rsrc(
-        want_coef ? d.d_coef + (int64_t)f * d.level_frame_stride : lvl_pl, 0, want_coef ? lvl_bytes : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (MODE & TQ_FWD) ? const_cast<uint8_t *>(d.d_src) + (int64_t)f * d.src_frame_stride : const_cast<uint8_t *>(pred_pl), 0,
-        (MODE & TQ_FWD) ? (uint32_t)((int64_t)(d.height - 1) * d.src_stride + d.width) : 0u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rec_rs = __builtin_amdgcn_make_buffer_rsrc(
-        (MODE & TQ_INV) ? d.d_rec + (int64_t)f * d.rec_frame_stride : const_cast<uint8_t *>(pred_pl), 0,
-        (MODE & TQ_INV) ? (uint32_t)((int64_t)(d.height - 1) * d.rec_stride + d.width) : 0u, 0x00020000);
     const bool want_sum = (MODE & TQ_FWD) && d.d_abs_sum;
-    const __amdgpu_buffer_rsrc_t sum_rs = __builtin_amdgcn_make_buffer_rsrc(
-        want_sum ? d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride : reinterpret_cast<uint32_t *>(lvl_pl), 0,
-        want_sum ? (uint32_t)((d.height >> L2) * (d.width >> L2)) * 4u : 0u, 0x00020000);
+    constexpr bool have_mv = MV;  // the launcher picks the instantiation: no branch on it between a load and its use
     const int row_bytes = d.level_stride * 2;
-    const x265amd_mv *mv_pl = d.d_mv ? d.d_mv + (int64_t)f * d.mv_frame_stride : nullptr;
     const int tus_x = d.width >> L2;
-    const int xh = x0 + 16 * h;                    // the lane's 16 bytes of a picture row start here
-    const bool half_ok = 16 * h < wvalid;
-    const bool col_ok = c < wvalid;                // lane = column c of the tile in the coefficient layout
-    const bool wide = (wvalid & 15) == 0;          // wave-uniform: the row halves are whole 16-byte pieces
 
-    const int ty_beg = blockIdx.y * kRowsPerWave;
-    const int ty_end = min(ty_beg + kRowsPerWave, p.tiles_y);
-
-    // the vectors of every tile of the run, fetched up front (only mvx | mvy: the first dword of x265amd_mv): the
-    // prediction loads that depend on them can then be issued a whole tile ahead
-    const __amdgpu_buffer_rsrc_t mv_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<x265amd_mv *>(mv_pl ? mv_pl : reinterpret_cast<const x265amd_mv *>(pred_pl)), 0,
-        mv_pl ? (uint32_t)(p.mv_ctus_x * (d.height >> p.mv_ctu_log2)) * 8u : 0u, 0x00020000);
-    uint32_t mvw[kRowsPerWave];
-#pragma unroll
-    for (int k = 0; k < kRowsPerWave; k++) mvw[k] = 0u;
-    if (mv_pl) {  // wave-uniform
-#pragma unroll
-        for (int k = 0; k < kRowsPerWave; k++) {
-            const int yk = (ty_beg + k) * 32 + c;
-            const bool ok = ty_beg + k < ty_end && yk < d.height && half_ok;
-            const uint32_t idx = ok ? (uint32_t)((yk >> p.mv_ctu_log2) * p.mv_ctus_x + (xh >> p.mv_ctu_log2)) : 0u;
-            mvw[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mv_rs, (int)(idx * 8u), 0, 0);  // entry 0 exists: the picture has a block
+    auto pred_rsrc = [&](int f) {
+        const uint8_t *pl = d.d_pred + (int64_t)f * d.pred_frame_stride;
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(reinterpret_cast<uintptr_t>(pl) - kPredBias), 0, 0xffffffffu,
+                                                 kRsrcFlags);
+    };
+    // per-lane geometry of the tile this wave takes in unit `pos`
+    struct Geo {
+        int x0, xh, wvalid;
+        bool tile_ok, half_ok, col_ok;
+    };
+    auto geo = [&](const TilePos &pos) {
+        Geo g;
+        const int tx = pos.txg * 4 + wave;
+        g.tile_ok = tx < p.tiles_x;                       // wave-uniform
+        g.x0 = tx * 32;
+        g.wvalid = g.tile_ok ? min(32, d.width - g.x0) : 0;  // a multiple of N
+        g.xh = g.x0 + 16 * h;                             // the lane's 16 bytes of a picture row start here
+        g.half_ok = 16 * h < g.wvalid;
+        g.col_ok = c < g.wvalid;                          // lane = column c of the tile in the coefficient layout
+        return g;
+    };
+    auto advance = [&](TilePos &pos) {
+        if (++pos.txg == ntxg) {
+            pos.txg = 0;
+            if (++pos.ty == p.tiles_y) {
+                pos.ty = 0;
+                pos.f++;
+            }
         }
-    }
-
-    // the lane's 16 bytes of its picture row (lane = row c of the tile, bytes 16 h .. 16 h + 15) of tile row `ty`
-    auto load_rows = [&](int ty, bool active, uint32_t mv, uint32_t (&sw)[4], uint32_t (&pw)[4]) {
-        const int y = ty * 32 + c;
-        const bool row_ok = active && y < d.height && half_ok;
+    };
+    // mvx | mvy (the first dword of x265amd_mv) of the lane's half row; mv_ctu >= 16: one vector per half row
+    auto load_mv = [&](const TilePos &pos, bool active) -> uint32_t {
+        if constexpr (!have_mv) return 0u;
+        const Geo g = geo(pos);
+        const int f = active ? pos.f : 0;
+        const __amdgpu_buffer_rsrc_t mv_rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<x265amd_mv *>(d.d_mv) + (int64_t)f * d.mv_frame_stride, 0, (uint32_t)(p.mv_ctus_x * (d.height >> p.mv_ctu_log2)) * 8u,
+            kRsrcFlags);
+        const int y = pos.ty * 32 + c;
+        const bool ok = active && y < d.height && g.half_ok;
+        const uint32_t idx = ok ? (uint32_t)((y >> p.mv_ctu_log2) * p.mv_ctus_x + (g.xh >> p.mv_ctu_log2)) : 0u;
+        return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mv_rs, (int)(idx * 8u), 0, 0);  // entry 0 exists
+    };
+    // the lane's 16 bytes of its picture row (lane = row c of the tile, bytes 16 h .. 16 h + 15)
+    auto load_rows = [&](const TilePos &pos, bool active, uint32_t mv, uint32_t (&sw)[4], uint32_t (&pw)[4]) {
+        const Geo g = geo(pos);
+        const int f = active ? pos.f : 0;
+        const __amdgpu_buffer_rsrc_t pred_rs = pred_rsrc(f);
+        const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+            (MODE & TQ_FWD) ? const_cast<uint8_t *>(d.d_src) + (int64_t)f * d.src_frame_stride : const_cast<uint8_t *>(d.d_pred), 0,
+            (MODE & TQ_FWD) ? (uint32_t)((int64_t)(d.height - 1) * d.src_stride + d.width) : 0u, kRsrcFlags);
+        const int y = pos.ty * 32 + c;
+        const bool row_ok = active && y < d.height && g.half_ok;
         // offset from the biased base, modulo 2^32: with vectors the prediction may lie above / left of d_pred, and
         // the wrap-around of unsigned arithmetic gives exactly the low 32 bits of the signed offset
-        uint32_t poff = (uint32_t)y * (uint32_t)d.pred_stride + (uint32_t)xh;
-        if (mv_pl) {  // wave-uniform; integer-pel motion compensation fused into the load (mv_ctu >= 16: one vector per half row)
+        uint32_t poff = (uint32_t)y * (uint32_t)d.pred_stride + (uint32_t)g.xh;
+        if constexpr (have_mv) {  // integer-pel motion compensation fused into the load
             const int mvx = (int)(int16_t)(mv & 0xffffu), mvy = (int)mv >> 16;
-            poff = (uint32_t)(y + (mvy >> d.mv_shift)) * (uint32_t)d.pred_stride + (uint32_t)(xh + (mvx >> d.mv_shift));
+            poff = (uint32_t)(y + (mvy >> d.mv_shift)) * (uint32_t)d.pred_stride + (uint32_t)(g.xh + (mvx >> d.mv_shift));
         }
         const uint32_t pofs = kPredBias + poff;
-        const uint32_t soff = (uint32_t)y * (uint32_t)d.src_stride + (uint32_t)xh;
-        if (wide) {  // wave-uniform
-            const v4i a = __builtin_amdgcn_raw_buffer_load_b128(pred_rs, (int)(row_ok ? pofs : kPredBias), 0, 0);
+        const uint32_t soff = (uint32_t)y * (uint32_t)d.src_stride + (uint32_t)g.xh;
+        // The plane's width is a multiple of 16 (the launcher sends other widths to the butterfly kernel), so a lane's
+        // 16 bytes are inside the row or not at all.  Idle lanes read the window's first bytes / zeros: what they
+        // hold never reaches a valid output (rows and columns past the picture belong to transform units that
+        // lie wholly outside it, and the matrices are block-diagonal per unit).  No select on the loaded VALUES:
+        // it would make the wave wait for them here, and these loads are a tile ahead of their use.
+        const v4i a = __builtin_amdgcn_raw_buffer_load_b128(pred_rs, (int)(row_ok ? pofs : kPredBias), 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; i++) pw[i] = row_ok ? (uint32_t)a[i] : 0u;
-            if constexpr (MODE & TQ_FWD) {
-                const v4i b = __builtin_amdgcn_raw_buffer_load_b128(src_rs, (int)(row_ok ? soff : kOob), 0, 0);
+        for (int i = 0; i < 4; i++) pw[i] = (uint32_t)a[i];
+        if constexpr (MODE & TQ_FWD) {
+            const v4i b = __builtin_amdgcn_raw_buffer_load_b128(src_rs, (int)(row_ok ? soff : kOob), 0, 0);
 #pragma unroll
-                for (int i = 0; i < 4; i++) sw[i] = (uint32_t)b[i];
-            }
-        } else {  // widths that are not a multiple of 16: dword by dword
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const bool ok = row_ok && xh + 4 * i < d.width;
-                const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pred_rs, (int)(ok ? pofs + 4 * i : kPredBias), 0, 0);
-                pw[i] = ok ? v : 0u;
-                if constexpr (MODE & TQ_FWD)
-                    sw[i] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(src_rs, (int)(ok ? soff + 4 * i : kOob), 0, 0);
-                else
-                    sw[i] = 0u;
-            }
+            for (int i = 0; i < 4; i++) sw[i] = (uint32_t)b[i];
         }
         if constexpr (!(MODE & TQ_FWD)) {
 #pragma unroll
@@ -257,18 +263,45 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
         }
     };
 
+    // ---- the walk over this workgroup's units ----
+    TilePos pos0;
+    {
+        const int upf = ntxg * p.tiles_y;
+        pos0.f = u_beg / upf;
+        const int rem = u_beg - pos0.f * upf;
+        pos0.ty = rem / ntxg;
+        pos0.txg = rem - pos0.ty * ntxg;
+        pos0.f = __builtin_amdgcn_readfirstlane(pos0.f);
+        pos0.ty = __builtin_amdgcn_readfirstlane(pos0.ty);
+        pos0.txg = __builtin_amdgcn_readfirstlane(pos0.txg);
+    }
+    TilePos pos1 = pos0;
+    advance(pos1);
+    TilePos pos2 = pos1;
+    advance(pos2);
     uint32_t srcw[4], predw[4], src_nx[4], pred_nx[4];
-    load_rows(ty_beg, true, mvw[0], srcw, predw);
-#pragma unroll
-    for (int k = 0; k < kRowsPerWave; k++) {
-        const int ty = ty_beg + k;
-        if (ty >= ty_end) break;  // wave-uniform
-        // the next tile's rows are on their way while this one is transformed (past the run's end: all lanes idle)
-        if (k + 1 < kRowsPerWave) load_rows(ty + 1, ty + 1 < ty_end, mvw[k + 1 < kRowsPerWave ? k + 1 : 0], src_nx, pred_nx);
-        const int y0 = ty * 32;
-        const int hvalid = min(32, d.height - y0);  // a multiple of N
+    load_rows(pos0, true, load_mv(pos0, true), srcw, predw);
+    uint32_t mv1 = load_mv(pos1, u_beg + 1 < u_end);
+    // everything loaded so far is waited for before the loop, so that inside it only its own prefetches are pending
+    asm volatile("" ::"v"(srcw[0]), "v"(srcw[1]), "v"(srcw[2]), "v"(srcw[3]), "v"(predw[0]), "v"(predw[1]), "v"(predw[2]),
+                 "v"(predw[3]), "v"(mv1), "v"(f1), "v"(f2), "v"(f3));
+
+#pragma unroll 1
+    for (int u = u_beg; u < u_end; u++) {
+        // the next unit's rows and the vectors of the one after it are on their way while this one is transformed
+        load_rows(pos1, u + 1 < u_end, mv1, src_nx, pred_nx);
+        const uint32_t mv2 = load_mv(pos2, u + 2 < u_end);
+
+        const Geo g = geo(pos0);
+        if (g.tile_ok) {  // wave-uniform (the last group of a tile row may hold fewer than four tiles)
+        const int f = pos0.f;
+        const int x0 = g.x0, xh = g.xh;
+        const bool col_ok = g.col_ok;
+        const int y0 = pos0.ty * 32;
         const int y = y0 + c;                       // lane = row c of the tile in the row layout
-        const bool row_ok = c < hvalid && half_ok;
+        const bool row_ok = y < d.height && g.half_ok;
+        int16_t *lvl_pl = d.d_level + (int64_t)f * d.level_frame_stride;
+        const __amdgpu_buffer_rsrc_t lvl_rs = __builtin_amdgcn_make_buffer_rsrc(lvl_pl, 0, lvl_bytes, kRsrcFlags);
 
         int level[16];  // the lane's column of quantised levels: x = x0 + c, y = y0 + rho(r, h)
         // byte offset of the lane's (column c, row 4 h) in the level / coefficient planes; register r adds rho(r, 0)
@@ -289,9 +322,9 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
             // comment on DC columns; split into bytes for the next product
             uint32_t mh[4], ml[4];
 #pragma unroll
-            for (int g = 0; g < 4; g++)
-                split4((uint32_t)acc[4 * g] >> sh1, (uint32_t)acc[4 * g + 1] >> sh1, (uint32_t)acc[4 * g + 2] >> sh1,
-                       (uint32_t)acc[4 * g + 3] >> sh1, mh[g], ml[g]);
+            for (int g4 = 0; g4 < 4; g4++)
+                split4((uint32_t)acc[4 * g4] >> sh1, (uint32_t)acc[4 * g4 + 1] >> sh1, (uint32_t)acc[4 * g4 + 2] >> sh1,
+                       (uint32_t)acc[4 * g4 + 3] >> sh1, mh[g4], ml[g4]);
             // ================= pass 2: T x M1 (columns) =================
             constexpr int rnd2 = 1 << (sh2 - 1);
             v16i ah = mfma(f2, as_v4i(mh), splat16(N >= 8 ? rnd2 >> 8 : 0));  // 256 * (rnd2 >> 8) = rnd2 for N >= 8
@@ -312,10 +345,18 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
                 psum[r >> 2] = sad_u32(lb, q_bias, psum[r >> 2]);
                 level[r] = (int)(lb - q_bias);
             }
+            // The prefetched rows (and vectors) are waited for HERE, before this tile's first store is issued: with
+            // loads and stores in flight together the wait could only be "everything", i.e. a round trip to memory
+            // per tile for the stores.  By now the loads have had the whole forward half of the tile to arrive.
+            // (level[15] among the operands keeps the scheduler from moving the wait up ahead of the quantiser.)
+            asm volatile("" ::"v"(src_nx[0]), "v"(src_nx[1]), "v"(src_nx[2]), "v"(src_nx[3]), "v"(pred_nx[0]), "v"(pred_nx[1]),
+                         "v"(pred_nx[2]), "v"(pred_nx[3]), "v"(mv2), "v"(level[15]), "v"(level[0]));
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 __builtin_amdgcn_raw_buffer_store_b16((short)level[r], lvl_rs, lv_off, rho(r, 0) * row_bytes, 0);
             if (want_coef) {  // wave-uniform; stage-by-stage checks only
+                const __amdgpu_buffer_rsrc_t coef_rs =
+                    __builtin_amdgcn_make_buffer_rsrc(d.d_coef + (int64_t)f * d.level_frame_stride, 0, lvl_bytes, kRsrcFlags);
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     __builtin_amdgcn_raw_buffer_store_b16((short)cf[r], coef_rs, lv_off, rho(r, 0) * row_bytes, 0);
@@ -340,6 +381,8 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
                     if constexpr (N >= 8) s[i] += __shfl_xor(s[i], 32);
                 }
                 // one lane per TU column writes; TU rows below the picture are past the end of the resource
+                const __amdgpu_buffer_rsrc_t sum_rs = __builtin_amdgcn_make_buffer_rsrc(
+                    d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride, 0, (uint32_t)((d.height >> L2) * (d.width >> L2)) * 4u, kRsrcFlags);
                 const bool writer = (c & (N - 1)) == 0 && (N == 4 || h == 0) && col_ok;
                 const uint32_t a_off = writer ? (uint32_t)((y0 >> L2) * tus_x + ((x0 + c) >> L2)) * 4u : kOob;
 #pragma unroll
@@ -358,14 +401,14 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
             // ================= xDeQuant (src/pixel.cpp:649-650): clip16((level * scale + rnd) >> shift) =================
             uint32_t dh[4], dl[4];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g4 = 0; g4 < 4; g4++) {
                 int v[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) v[k] = (mul24(level[4 * g + k], p.dq_scale) + p.dq_rnd) >> p.dq_shift;
+                for (int k = 0; k < 4; k++) v[k] = (mul24(level[4 * g4 + k], p.dq_scale) + p.dq_rnd) >> p.dq_shift;
                 // v_cvt_pk_i16_i32 saturates: the clip and the pack in one
                 const uint32_t p0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0], v[1]));
                 const uint32_t p1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2], v[3]));
-                split2x2(p0, p1, dh[g], dl[g]);
+                split2x2(p0, p1, dh[g4], dl[g4]);
             }
             // ================= inverse pass 1 (columns): coefficients^T x T =================
             v16i ah = mfma(as_v4i(dh), f3, splat16(0));
@@ -373,11 +416,11 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
             // (sum + 64) >> 7, store-then-clip = wrap (src/pixel.cpp:334-342); lane = picture row now
             uint32_t uh[4], ul[4];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g4 = 0; g4 < 4; g4++) {
                 uint32_t t[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) t[k] = (((uint32_t)ah[4 * g + k] << 8) + (uint32_t)al[4 * g + k]) >> 7;
-                split4(t[0], t[1], t[2], t[3], uh[g], ul[g]);
+                for (int k = 0; k < 4; k++) t[k] = (((uint32_t)ah[4 * g4 + k] << 8) + (uint32_t)al[4 * g4 + k]) >> 7;
+                split4(t[0], t[1], t[2], t[3], uh[g4], ul[g4]);
             }
             // ================= inverse pass 2 (rows): T^T x intermediate =================
             ah = mfma(f3, as_v4i(uh), splat16(0));
@@ -389,61 +432,76 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
             const uint32_t pg[4] = {pq[0], pq[2], pq[1], pq[3]};
             uint32_t rq[4];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
+            for (int g4 = 0; g4 < 4; g4++) {
                 // (sum + 2048) >> 12, wrap (truncating pack), + pred, Clip (src/pixel.cpp:757-761): the saturating
                 // Int16 add cannot change a sum that is clipped to 0..255 anyway
                 uint32_t t[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) t[k] = (((uint32_t)ah[4 * g + k] << 8) + (uint32_t)al[4 * g + k]) << 4;
+                for (int k = 0; k < 4; k++) t[k] = (((uint32_t)ah[4 * g4 + k] << 8) + (uint32_t)al[4 * g4 + k]) << 4;
                 const v2s r0 = __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, perm(t[1], t[0], 0x07060302u)),
-                                                             __builtin_bit_cast(v2s, perm(0u, pg[g], 0x0c010c00u)));
+                                                             __builtin_bit_cast(v2s, perm(0u, pg[g4], 0x0c010c00u)));
                 const v2s r1 = __builtin_elementwise_add_sat(__builtin_bit_cast(v2s, perm(t[3], t[2], 0x07060302u)),
-                                                             __builtin_bit_cast(v2s, perm(0u, pg[g], 0x0c030c02u)));
-                rq[g] = perm(sat_pk_u8_i16(__builtin_bit_cast(uint32_t, r1)), sat_pk_u8_i16(__builtin_bit_cast(uint32_t, r0)),
-                             0x05040100u);
+                                                             __builtin_bit_cast(v2s, perm(0u, pg[g4], 0x0c030c02u)));
+                rq[g4] = perm(sat_pk_u8_i16(__builtin_bit_cast(uint32_t, r1)), sat_pk_u8_i16(__builtin_bit_cast(uint32_t, r0)),
+                              0x05040100u);
             }
             // back to "16 consecutive bytes per lane": dwords 4 h .. 4 h + 3
             uint32_t ro[4] = {rq[0], rq[2], rq[1], rq[3]};  // dword h, 4 + h, 2 + h, 6 + h
             swap32(ro[0], ro[1]);  // -> dwords 4 h, 4 h + 1
             swap32(ro[2], ro[3]);  // -> dwords 4 h + 2, 4 h + 3
+            const __amdgpu_buffer_rsrc_t rec_rs = __builtin_amdgcn_make_buffer_rsrc(
+                d.d_rec + (int64_t)f * d.rec_frame_stride, 0, (uint32_t)((int64_t)(d.height - 1) * d.rec_stride + d.width), kRsrcFlags);
             const uint32_t off = (uint32_t)y * (uint32_t)d.rec_stride + (uint32_t)xh;
-            if (wide) {  // wave-uniform
-                __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)ro[0], (int)ro[1], (int)ro[2], (int)ro[3]}, rec_rs,
-                                                      (int)(row_ok ? off : kOob), 0, 0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-                    __builtin_amdgcn_raw_buffer_store_b32((int)ro[i], rec_rs, (int)(row_ok && xh + 4 * i < d.width ? off + 4 * i : kOob), 0, 0);
-            }
+            __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)ro[0], (int)ro[1], (int)ro[2], (int)ro[3]}, rec_rs, (int)(row_ok ? off : kOob), 0, 0);
+        }
+        } else {  // the same wait on the path that skips the tile
+            asm volatile("" ::"v"(src_nx[0]), "v"(src_nx[1]), "v"(src_nx[2]), "v"(src_nx[3]), "v"(pred_nx[0]), "v"(pred_nx[1]),
+                         "v"(pred_nx[2]), "v"(pred_nx[3]), "v"(mv2));
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             srcw[i] = src_nx[i];
             predw[i] = pred_nx[i];
         }
+        mv1 = mv2;
+        pos0 = pos1;
+        pos1 = pos2;
+        advance(pos2);
     }
 }
 
-template <int MODE> static void launch_n(int tu, dim3 grid, hipStream_t stream, const TqParams &p)
+template <int MODE, bool MV> static void launch_n(int tu, dim3 grid, hipStream_t stream, const TqParams &p)
 {
     switch (tu) {
-    case 4: hipLaunchKernelGGL((tq_mfma_kernel<4, MODE>), grid, dim3(256), 0, stream, p); break;
-    case 8: hipLaunchKernelGGL((tq_mfma_kernel<8, MODE>), grid, dim3(256), 0, stream, p); break;
-    case 16: hipLaunchKernelGGL((tq_mfma_kernel<16, MODE>), grid, dim3(256), 0, stream, p); break;
-    default: hipLaunchKernelGGL((tq_mfma_kernel<32, MODE>), grid, dim3(256), 0, stream, p); break;
+    case 4: hipLaunchKernelGGL((tq_mfma_kernel<4, MODE, MV>), grid, dim3(256), 0, stream, p); break;
+    case 8: hipLaunchKernelGGL((tq_mfma_kernel<8, MODE, MV>), grid, dim3(256), 0, stream, p); break;
+    case 16: hipLaunchKernelGGL((tq_mfma_kernel<16, MODE, MV>), grid, dim3(256), 0, stream, p); break;
+    default: hipLaunchKernelGGL((tq_mfma_kernel<32, MODE, MV>), grid, dim3(256), 0, stream, p); break;
     }
 }
+template <int MODE> static void launch_mv(dim3 grid, hipStream_t stream, const TqParams &p)
+{
+    if (p.d.d_mv)
+        launch_n<MODE, true>(p.d.tu, grid, stream, p);
+    else
+        launch_n<MODE, false>(p.d.tu, grid, stream, p);
+}
 
+// grid = the workgroups the chip holds at once (kWgPerCu per CU: four waves per SIMD), or fewer when there is
+// less work than that; the kernel splits the units evenly over whatever grid it is given
 int launch_tq_mfma(int mode, const TqParams &p, hipStream_t stream)
 {
-    if (p.d.nframes > 65535) return X265AMD_ERR_ARG;  // grid.z
-    const dim3 grid((unsigned)((p.tiles_x + 3) / 4), (unsigned)((p.tiles_y + kRowsPerWave - 1) / kRowsPerWave), (unsigned)p.d.nframes);
+    constexpr int kWgPerCu = 4;
+    const int64_t units = (int64_t)((p.tiles_x + 3) / 4) * p.tiles_y * p.d.nframes;
+    if (units > 0x7fffffff) return X265AMD_ERR_ARG;
+    const int64_t resident = (int64_t)cu_count() * kWgPerCu;
+    const dim3 grid((unsigned)(units < resident ? units : resident));
     if (mode == TQ_FWD)
-        launch_n<TQ_FWD>(p.d.tu, grid, stream, p);
+        launch_mv<TQ_FWD>(grid, stream, p);
     else if (mode == TQ_INV)
-        launch_n<TQ_INV>(p.d.tu, grid, stream, p);
+        launch_mv<TQ_INV>(grid, stream, p);
     else
-        launch_n<TQ_BOTH>(p.d.tu, grid, stream, p);
+        launch_mv<TQ_BOTH>(grid, stream, p);
     return hip_status(hipGetLastError());
 }
 
