@@ -36,6 +36,17 @@ void x265amd_debug_sea_shape(int lds_pad_bytes, int waves);
  * two are independent formulations of the same arithmetic and must agree bit for bit */
 void x265amd_debug_tq_path(int path);
 
+/* Where and when the waves of the matrix-core TQ kernel ran: with a non-null device buffer of nwaves x 4
+ * 64-bit words (nwaves >= 4 x the workgroups of the launch, else nothing is recorded; zeroed by the caller) every wave of the following
+ * launches of that kernel leaves {start, end (100 MHz wall clock), shader clocks spent,
+ * XCC_ID << 32 | HW_ID} at record 4 * workgroup + wave.  Null switches it off.  Process-wide like the hooks
+ * above; tools/tq_trace.py prints the launch ramp, the spread of the durations and the clock from it. */
+void x265amd_debug_tq_trace(unsigned long long *d_records, int nwaves);
+
+/* Tile units (4 neighbouring 32x32 tiles) per workgroup of the matrix-core TQ kernel: 0 (default) = an even
+ * split over the workgroups the chip holds at once; n > 0 = n units per workgroup.  For tuning runs. */
+void x265amd_debug_tq_units_per_wg(int n);
+
 /* x265amd_me_fullsearch in its independent one-candidate-per-lane formulation (v_alignbyte_b32 + v_sad_u8,
  * current block in LDS): the cross-check of the production kernels, 1.0-1.6 Gpix/s */
 int x265amd_debug_me_fullsearch_basic(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height, int stride,

@@ -31,7 +31,7 @@ def main():
     workload, d = sys.argv[1], sys.argv[2]
     out = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(__file__), "..", "profiles", "r1_pmc_sq.json")
     merged = defaultdict(dict)
-    for sub in ("a", "b", "c"):
+    for sub in ("a", "b", "c", "d"):
         for k, v in load(os.path.join(d, sub)).items():
             merged[k].update(v)
     res = {}

@@ -100,6 +100,8 @@ DEBUG_SIGNATURES = {
     "x265amd_debug_me_last_ms": (C.c_int, [C.POINTER(C.c_float)]),
     "x265amd_debug_sea_shape": (None, [C.c_int, C.c_int]),
     "x265amd_debug_tq_path": (None, [C.c_int]),
+    "x265amd_debug_tq_trace": (None, [C.c_void_p, C.c_int]),
+    "x265amd_debug_tq_units_per_wg": (None, [C.c_int]),
     "x265amd_debug_me_fullsearch_basic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                      C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                                      C.c_void_p]),

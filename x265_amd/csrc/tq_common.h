@@ -14,6 +14,8 @@ struct TqParams {
     unsigned q_rnd;
     int dq_scale, dq_shift, dq_rnd;
     int mv_ctu_log2, mv_ctus_x;    // with d.d_mv: log2 of d.mv_ctu, vectors per picture row
+    unsigned long long *d_trace;   // x265amd_debug_tq_trace: four 64-bit words per wave of tq_mfma_kernel, or null
+    int trace_waves;               // .. and how many waves it has room for
 };
 
 enum { TQ_FWD = 1, TQ_INV = 2, TQ_BOTH = 3 };

@@ -393,6 +393,8 @@ static void quant_constants(int tu, int qp, int slice_type, TqParams &p)
 
 // debugging aid (include/x265_amd_debug.h): 0 = the library's choice, 1 = always the butterfly kernel
 static int g_tq_path = 0;
+static unsigned long long *g_tq_trace = nullptr;
+static int g_tq_trace_waves = 0;
 
 template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_t stream, bool coef_in = false)
 {
@@ -434,6 +436,8 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     quant_constants(d.tu, d.qp, d.slice_type, p);
     p.mv_ctu_log2 = d.d_mv ? ilog2(d.mv_ctu) : 0;
     p.mv_ctus_x = d.d_mv ? d.width / d.mv_ctu : 0;
+    p.d_trace = g_tq_trace;
+    p.trace_waves = g_tq_trace_waves;
     if (coef_in) {  // the plane already holds xDeQuant's output: (c * 1 + 0) >> 0, and the clip is a no-op on Int16
         p.dq_scale = 1;
         p.dq_rnd = 0;
@@ -442,7 +446,11 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     // the matrix-core formulation (tq_mfma.hip) wherever the transform matrix is the same for every TU of the
     // plane and the rows split into 16-byte pieces; per-TU DST selection at 4x4 (d_modes), widths that are not a
     // multiple of 16 and the debug switch keep the butterfly kernel
-    if (g_tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0) return launch_tq_mfma(MODE, p, stream);
+    // .. and so do planes whose strides or height do not fit the 24-bit multiplies of its address arithmetic
+    const int kLim = 1 << 23;
+    const bool small = d.height < kLim && d.level_stride < kLim && d.pred_stride < kLim && d.src_stride < kLim &&
+                       d.rec_stride < kLim;
+    if (g_tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0 && small) return launch_tq_mfma(MODE, p, stream);
     const dim3 grid((unsigned)((nt + 7) / 8)), block(256);
     switch (d.tu) {
     case 4: hipLaunchKernelGGL((tq_kernel<4, MODE>), grid, block, 0, stream, p); break;
@@ -458,6 +466,11 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
 using namespace x265amd;
 
 extern "C" void x265amd_debug_tq_path(int path) { g_tq_path = path; }
+extern "C" void x265amd_debug_tq_trace(unsigned long long *d_records, int nwaves)
+{
+    g_tq_trace = d_records;
+    g_tq_trace_waves = d_records ? nwaves : 0;
+}
 
 extern "C" int x265amd_tq_forward(const x265amd_tq_desc *desc, void *stream)
 {

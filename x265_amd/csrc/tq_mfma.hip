@@ -107,6 +107,22 @@ __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc
     asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc));
     return r;
 }
+// row * stride for a byte offset: both below 2^23 in magnitude (launch_tq sends other planes to the butterfly
+// kernel), so the full-rate 24-bit multiply is exact; the 32-bit one runs at a quarter of the rate
+__device__ __forceinline__ int rowmul(int row, int stride) { return __mul24(row, stride); }
+// bits [lo, lo + 16) of t, sign-extended: v_bfe_i32 (written out: left to itself the compiler shifts the word up
+// front instead and pays an instruction more per coefficient)
+template <int LO> __device__ __forceinline__ int field16(int t)
+{
+    int r;
+    asm("v_bfe_i32 %0, %1, %2, 16" : "=v"(r) : "v"(t), "n"(LO));
+    return r;
+}
+// x + (x of the lane that the DPP pattern CTRL names); rows outside ROW_MASK add nothing
+template <int CTRL, int ROW_MASK = 0xf> __device__ __forceinline__ uint32_t dpp_add(uint32_t x)
+{
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
 __device__ __forceinline__ void swap32(uint32_t &x, uint32_t &y)  // x's upper half-wave <-> y's lower half-wave
 {
     const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
@@ -135,6 +151,24 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
+
+    // x265amd_debug_tq_trace: when and where this wave ran (wave-uniform branch, off in normal use)
+    unsigned long long t_wall0 = 0, t_clk0 = 0;
+    if (p.d_trace) {
+        t_wall0 = wall_clock64();  // 100 MHz
+        t_clk0 = clock64();        // shader clock
+    }
+    auto trace_end = [&]() {
+        if (p.d_trace && lane == 0) {
+            unsigned long long *rec = p.d_trace + ((size_t)blockIdx.x * 4 + wave) * 4;
+            const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+            const unsigned xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
+            rec[0] = t_wall0;
+            rec[1] = wall_clock64();
+            rec[2] = clock64() - t_clk0;
+            rec[3] = ((unsigned long long)xcc_id << 32) | hw_id;
+        }
+    };
 
     const int ntxg = (p.tiles_x + 3) >> 2;
     const int nunits = ntxg * p.tiles_y * d.nframes;
@@ -222,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
             kRsrcFlags);
         const int y = pos.ty * 32 + c;
         const bool ok = active && y < d.height && g.half_ok;
-        const uint32_t idx = ok ? (uint32_t)((y >> p.mv_ctu_log2) * p.mv_ctus_x + (g.xh >> p.mv_ctu_log2)) : 0u;
+        const uint32_t idx = ok ? (uint32_t)(rowmul(y >> p.mv_ctu_log2, p.mv_ctus_x) + (g.xh >> p.mv_ctu_log2)) : 0u;
         return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mv_rs, (int)(idx * 8u), 0, 0);  // entry 0 exists
     };
     // the lane's 16 bytes of its picture row (lane = row c of the tile, bytes 16 h .. 16 h + 15)
@@ -237,13 +271,13 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
         const bool row_ok = active && y < d.height && g.half_ok;
         // offset from the biased base, modulo 2^32: with vectors the prediction may lie above / left of d_pred, and
         // the wrap-around of unsigned arithmetic gives exactly the low 32 bits of the signed offset
-        uint32_t poff = (uint32_t)y * (uint32_t)d.pred_stride + (uint32_t)g.xh;
+        uint32_t poff = (uint32_t)rowmul(y, d.pred_stride) + (uint32_t)g.xh;
         if constexpr (have_mv) {  // integer-pel motion compensation fused into the load
             const int mvx = (int)(int16_t)(mv & 0xffffu), mvy = (int)mv >> 16;
-            poff = (uint32_t)(y + (mvy >> d.mv_shift)) * (uint32_t)d.pred_stride + (uint32_t)(g.xh + (mvx >> d.mv_shift));
+            poff = (uint32_t)rowmul(y + (mvy >> d.mv_shift), d.pred_stride) + (uint32_t)(g.xh + (mvx >> d.mv_shift));
         }
         const uint32_t pofs = kPredBias + poff;
-        const uint32_t soff = (uint32_t)y * (uint32_t)d.src_stride + (uint32_t)g.xh;
+        const uint32_t soff = (uint32_t)rowmul(y, d.src_stride) + (uint32_t)g.xh;
         // The plane's width is a multiple of 16 (the launcher sends other widths to the butterfly kernel), so a lane's
         // 16 bytes are inside the row or not at all.  Idle lanes read the window's first bytes / zeros: what they
         // hold never reaches a valid output (rows and columns past the picture belong to transform units that
@@ -307,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
         // byte offset of the lane's (column c, row 4 h) in the level / coefficient planes; register r adds rho(r, 0)
         // rows through the scalar offset.  Lanes outside the plane's width are sent past the end; rows past its
         // height ARE past the end of the resource.
-        const int lv_off = col_ok ? (int)(((uint32_t)(y0 + 4 * h) * (uint32_t)d.level_stride + (uint32_t)(x0 + c)) * 2u) : (int)kOob;
+        const int lv_off = col_ok ? (int)(((uint32_t)rowmul(y0 + 4 * h, d.level_stride) + (uint32_t)(x0 + c)) * 2u) : (int)kOob;
         if constexpr (MODE & TQ_FWD) {
             // ================= pass 1: residual x T^T (rows of the tile) =================
             uint32_t sa[4], pa[4];
@@ -338,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
             for (int r = 0; r < 16; r++) {
                 int t = (int)(((uint32_t)ah[r] << 8) + (uint32_t)al[r]);
                 if constexpr (N == 4) t += rnd2;
-                cf[r] = __builtin_amdgcn_sbfe(t, sh2, 16);  // truncating Int16 store of the coefficient
+                cf[r] = field16<sh2>(t);  // truncating Int16 store of the coefficient
                 // xQuant
                 const int q = mul24(cf[r], (int)p.q_scale) + (cf[r] < 0 ? q_neg : q_pos);
                 const uint32_t lb = (uint32_t)q >> p.q_bits;   // level + q_bias
@@ -374,16 +408,29 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
 #pragma unroll
                     for (int q4 = 0; q4 < 4; q4++) s[q4] = psum[q4];
                 }
+                // sum over the lanes of a TU column (c / N) -- and over both h unless N = 4, where h tells TU rows apart --
+                // with DPP adds inside rows of 16 lanes (quads, halves, the row) and, past that, the two steps of
+                // the classic wave reduction for N = 32 (the total arrives in the last row) or one exchange of the
+                // wave's halves for N = 8, 16
 #pragma unroll
                 for (int i = 0; i < ns; i++) {
-#pragma unroll
-                    for (int o = 1; o < N && o < 32; o <<= 1) s[i] += __shfl_xor(s[i], o);
-                    if constexpr (N >= 8) s[i] += __shfl_xor(s[i], 32);
+                    s[i] = dpp_add<0xb1>(s[i]);                          // quad_perm [1,0,3,2]
+                    s[i] = dpp_add<0x4e>(s[i]);                          // quad_perm [2,3,0,1]
+                    if constexpr (N >= 8) s[i] = dpp_add<0x141>(s[i]);   // row_half_mirror
+                    if constexpr (N >= 16) s[i] = dpp_add<0x140>(s[i]);  // row_mirror
+                    if constexpr (N == 32) {
+                        s[i] = dpp_add<0x142, 0xa>(s[i]);  // row_bcast15: rows 1, 3 += row 0, 2
+                        s[i] = dpp_add<0x143, 0xc>(s[i]);  // row_bcast31: rows 2, 3 += rows 0 + 1
+                    } else if constexpr (N >= 8) {
+                        uint32_t lo = s[i], hi = s[i];
+                        swap32(lo, hi);  // lo = {lower half, lower half}, hi = {upper half, upper half}
+                        s[i] = lo + hi;
+                    }
                 }
                 // one lane per TU column writes; TU rows below the picture are past the end of the resource
                 const __amdgpu_buffer_rsrc_t sum_rs = __builtin_amdgcn_make_buffer_rsrc(
                     d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride, 0, (uint32_t)((d.height >> L2) * (d.width >> L2)) * 4u, kRsrcFlags);
-                const bool writer = (c & (N - 1)) == 0 && (N == 4 || h == 0) && col_ok;
+                const bool writer = (N == 32 ? lane == 63 : (c & (N - 1)) == 0 && (N == 4 || h == 0)) && col_ok;
                 const uint32_t a_off = writer ? (uint32_t)((y0 >> L2) * tus_x + ((x0 + c) >> L2)) * 4u : kOob;
 #pragma unroll
                 for (int i = 0; i < ns; i++) {
@@ -451,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
             swap32(ro[2], ro[3]);  // -> dwords 4 h + 2, 4 h + 3
             const __amdgpu_buffer_rsrc_t rec_rs = __builtin_amdgcn_make_buffer_rsrc(
                 d.d_rec + (int64_t)f * d.rec_frame_stride, 0, (uint32_t)((int64_t)(d.height - 1) * d.rec_stride + d.width), kRsrcFlags);
-            const uint32_t off = (uint32_t)y * (uint32_t)d.rec_stride + (uint32_t)xh;
+            const uint32_t off = (uint32_t)rowmul(y, d.rec_stride) + (uint32_t)xh;
             __builtin_amdgcn_raw_buffer_store_b128(v4i{(int)ro[0], (int)ro[1], (int)ro[2], (int)ro[3]}, rec_rs, (int)(row_ok ? off : kOob), 0, 0);
         }
         } else {  // the same wait on the path that skips the tile
@@ -468,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
         pos1 = pos2;
         advance(pos2);
     }
+    trace_end();
 }
 
 template <int MODE, bool MV> static void launch_n(int tu, dim3 grid, hipStream_t stream, const TqParams &p)
@@ -487,15 +535,22 @@ template <int MODE> static void launch_mv(dim3 grid, hipStream_t stream, const T
         launch_n<MODE, false>(p.d.tu, grid, stream, p);
 }
 
-// grid = the workgroups the chip holds at once (kWgPerCu per CU: four waves per SIMD), or fewer when there is
-// less work than that; the kernel splits the units evenly over whatever grid it is given
-int launch_tq_mfma(int mode, const TqParams &p, hipStream_t stream)
+// Units per workgroup.  0 = an even split over the workgroups the chip holds at once (four per CU: four waves per
+// SIMD); n > 0 = n units per workgroup, the dispatcher handing out workgroups as others finish.
+static int g_units_per_wg = 0;
+extern "C" void x265amd_debug_tq_units_per_wg(int n) { g_units_per_wg = n < 0 ? 0 : n; }
+
+int launch_tq_mfma(int mode, const TqParams &p_in, hipStream_t stream)
 {
     constexpr int kWgPerCu = 4;
+    TqParams p = p_in;
     const int64_t units = (int64_t)((p.tiles_x + 3) / 4) * p.tiles_y * p.d.nframes;
     if (units > 0x7fffffff) return X265AMD_ERR_ARG;
     const int64_t resident = (int64_t)cu_count() * kWgPerCu;
-    const dim3 grid((unsigned)(units < resident ? units : resident));
+    int64_t nwg = units < resident ? units : resident;
+    if (g_units_per_wg > 0) nwg = (units + g_units_per_wg - 1) / g_units_per_wg;
+    if (p.trace_waves < nwg * 4) p.d_trace = nullptr;
+    const dim3 grid((unsigned)nwg);
     if (mode == TQ_FWD)
         launch_mv<TQ_FWD>(grid, stream, p);
     else if (mode == TQ_INV)
