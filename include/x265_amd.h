@@ -183,6 +183,32 @@ int x265amd_me_fullsearch_pu(const uint8_t *d_cur, const uint8_t *d_ref, int wid
                              int nrefs, int64_t ref_ref_stride, x265amd_mv *d_out64, x265amd_mv *d_out32,
                              x265amd_mv *d_out16, void *stream);
 
+/* EVERY inter PU shape of every CTU in one exhaustive pass (remainder: 8x8 leaves and the
+ * rectangular PUs 2NxN / Nx2N at 64, 32 and 16): 169 PUs per 64x64 CTU, all sums of its sixty-four 8x8 SADs at a
+ * displacement -- the reference's primitives take any number of rows, xSadN[log2(w) - 2](h, ..)
+ * (src/pixel.cpp:30-101).  d_out: HOST array of X265AMD_PU_SHAPES device pointers, indexed by x265amd_pu_shape;
+ * entry s receives, for plane (f, r) at offset (f * nrefs + r) * (width / w_s) * (height / h_s), the raster of
+ * the w_s x h_s blocks tiling the picture: for each the first strict SAD minimum in raster order over the
+ * displacements that keep THAT block inside the picture (src/encode.cpp:725-727, 762-765), i.e. what
+ * x265amd_me_fullsearch returns for the square shapes.  Entries may be NULL (not all).  width, height multiples
+ * of 64; range <= 181; the unclipped (64 + 2*range)^2 window must fit in LDS, else X265AMD_ERR_LDS. */
+enum x265amd_pu_shape {
+    X265AMD_PU_64x64 = 0,
+    X265AMD_PU_64x32,
+    X265AMD_PU_32x64,
+    X265AMD_PU_32x32,
+    X265AMD_PU_32x16,
+    X265AMD_PU_16x32,
+    X265AMD_PU_16x16,
+    X265AMD_PU_16x8,
+    X265AMD_PU_8x16,
+    X265AMD_PU_8x8,
+    X265AMD_PU_SHAPES
+};
+int x265amd_me_fullsearch_pu_all(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height, int stride,
+                                 int range, int nframes, int64_t cur_frame_stride, int64_t ref_frame_stride,
+                                 int nrefs, int64_t ref_ref_stride, x265amd_mv *const *d_out, void *stream);
+
 /* -------------------------------------------------------- transform/quant */
 
 /* One descriptor for the three TQ entry points.  Planes are batched over

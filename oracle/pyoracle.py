@@ -70,6 +70,10 @@ class _Lib:
         self._me.restype = None
         self._me.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_int, C.c_int, C.c_int, C.c_int]
+        self._me_wh = g("me_fullsearch_wh")
+        self._me_wh.restype = None
+        self._me_wh.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                C.c_int, C.c_int, C.c_int, C.c_int]
         self._dct_matrix = g("dct_matrix")
         self._dct_matrix.restype = C.POINTER(C.c_int8)
         self._dct_matrix.argtypes = [C.c_int]
@@ -137,6 +141,15 @@ class _Lib:
         out = np.zeros((h // ctu) * (w // ctu), MV_DTYPE)
         self._me(_p(_chk(cur, np.uint8), _u8p), _p(_chk(ref, np.uint8), _u8p), w, h, w, ctu, rng,
                  out.ctypes.data, first, step, count, nthreads)
+        return out
+
+    def me_fullsearch_wh(self, cur, ref, bw, bh, rng, first=0, step=1, count=-1, nthreads=1):
+        """The same for bw x bh blocks tiling the picture.  Returns MV_DTYPE[H / bh][W / bw]."""
+        h, w = cur.shape
+        assert ref.shape == cur.shape and w % bw == 0 and h % bh == 0
+        out = np.zeros(((h // bh), (w // bw)), MV_DTYPE)
+        self._me_wh(_p(_chk(cur, np.uint8), _u8p), _p(_chk(ref, np.uint8), _u8p), w, h, w, bw, bh, rng,
+                    out.ctypes.data, first, step, count, nthreads)
         return out
 
 

@@ -125,6 +125,42 @@ void ref_me_fullsearch(const uint8_t *cur, const uint8_t *ref, int width, int he
     }
 }
 
+/* The same for bw x bh blocks tiling the picture: the reference's primitive for width bw called with bh rows. */
+void ref_me_fullsearch_wh(const uint8_t *cur, const uint8_t *ref, int width, int height, int stride,
+                          int bw, int bh, int range, ref_mv *out, int first, int step, int count,
+                          int nthreads)
+{
+    const int nbx = width / bw, nby = height / bh, nb = nbx * nby;
+    xSad *sad = xSadN[xLog2(bw - 1) - 2];
+    if (step < 1) step = 1;
+    if (count < 0) count = (nb - first + step - 1) / step;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
+    for (int i = 0; i < count; i++) {
+        int idx = first + i * step;
+        if (idx >= nb) continue;
+        const int bx0 = (idx % nbx) * bw, by0 = (idx / nbx) * bh;
+        UInt32 best = MAX_SAD;
+        int bx = 0, by = 0;
+        for (int dy = -range; dy <= range; dy++) {
+            if (by0 + dy < 0 || by0 + dy + bh > height) continue;
+            for (int dx = -range; dx <= range; dx++) {
+                if (bx0 + dx < 0 || bx0 + dx + bw > width) continue;
+                UInt32 c = sad(bh, cur + (size_t)by0 * stride + bx0, stride,
+                               ref + (size_t)(by0 + dy) * stride + bx0 + dx, stride);
+                if (c < best) {
+                    best = c;
+                    bx = dx;
+                    by = dy;
+                }
+            }
+        }
+        out[idx].mvx = (int16_t)bx;
+        out[idx].mvy = (int16_t)by;
+        out[idx].sad = best;
+    }
+}
+
 static void fetch(uint8_t *d, const uint8_t *p, int ps, const ref_mv *mv, int mv_ctu, int ncx,
                   int x0, int y0, int n)
 {

@@ -308,6 +308,43 @@ void orc_me_fullsearch(const uint8_t *cur, const uint8_t *ref, int width, int he
     }
 }
 
+/* The same search for w x h blocks tiling the picture (the inter PU shapes: 2NxN, Nx2N and the squares down
+ * to 8x8).  The reference's SAD primitives take the number of rows as an argument, xSadN[log2(w) - 2](h, ..)
+ * (src/pixel.cpp:30-101), so a rectangular PU is the same call with h != w; argmin idiom as above. */
+void orc_me_fullsearch_wh(const uint8_t *cur, const uint8_t *ref, int width, int height, int stride,
+                          int bw, int bh, int range, orc_mv *out, int first, int step, int count,
+                          int nthreads)
+{
+    const int nbx = width / bw, nby = height / bh, nb = nbx * nby;
+    if (step < 1) step = 1;
+    if (count < 0) count = (nb - first + step - 1) / step;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
+    for (int i = 0; i < count; i++) {
+        int idx = first + i * step;
+        if (idx >= nb) continue;
+        const int bx0 = (idx % nbx) * bw, by0 = (idx / nbx) * bh;
+        const uint8_t *c = cur + (size_t)by0 * stride + bx0;
+        uint32_t best = ORC_MAX_SAD;
+        int bx = 0, by = 0;
+        for (int dy = -range; dy <= range; dy++) {
+            if (by0 + dy < 0 || by0 + dy + bh > height) continue;
+            for (int dx = -range; dx <= range; dx++) {
+                if (bx0 + dx < 0 || bx0 + dx + bw > width) continue;
+                uint32_t cost = orc_sad(bw, bh, c, stride, ref + (size_t)(by0 + dy) * stride + bx0 + dx, stride);
+                if (cost < best) {
+                    best = cost;
+                    bx = dx;
+                    by = dy;
+                }
+            }
+        }
+        out[idx].mvx = (int16_t)bx;
+        out[idx].mvy = (int16_t)by;
+        out[idx].sad = best;
+    }
+}
+
 /* ------------------------------------------------------------------------ */
 /* Frame-level TQ.  Each TU is copied into 32-stride scratch exactly like    */
 /* the reference's per-CU cache (inc/x265.h:105-131) and run through the     */

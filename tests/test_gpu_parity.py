@@ -492,6 +492,58 @@ def test_me_pu_tree_equals_per_size_kernels_batched(gpu):
     assert torch.equal(only16[16], got[16]) and list(only16) == [16]
 
 
+def test_me_all_pu_shapes_vs_oracle(gpu, oracle):
+    """x265amd_me_fullsearch_pu_all: the ten inter PU shapes (squares 64 .. 8, 2NxN and Nx2N at 64 / 32 / 16) in
+    one pass == the oracle's exhaustive search of the w x h blocks tiling the picture (the reference's xSadN with
+    h rows).  Small pictures: every CTU touches a border, so the per-PU legality is what is tested; a range larger
+    than the picture allows, range 0 and a range that is not a multiple of the four-wide groups included; flat
+    patches for the ties."""
+    from x265_amd import synth
+    for (W, H, R, seed) in ((128, 64, 20, 3), (192, 128, 9, 4), (64, 64, 70, 5), (128, 128, 0, 6), (192, 192, 33, 7)):
+        seq = synth.make_sequence(W, H, 2, search_range=max(2, min(R, 16)), seed=seed)
+        seq[1, 8:40, 16:80] = 90
+        seq[0, 0:56, 8:100] = 90
+        got = gpu.me_fullsearch_pu_all(dev(seq[1]), dev(seq[0]), R)
+        assert list(got) == list(gpu.PU_SHAPES)
+        for (bw, bh) in gpu.PU_SHAPES:
+            want = oracle.me_fullsearch_wh(seq[1], seq[0], bw, bh, R, nthreads=16)
+            np.testing.assert_array_equal(gpu.mv_to_numpy(got[(bw, bh)])[0, 0], want, f"{W}x{H} R{R} PU {bw}x{bh}")
+
+
+def test_me_all_pu_shapes_interior_and_batched(gpu, oracle):
+    """A picture with interior CTUs (the path without legality arithmetic) next to border ones, frames x
+    references in one launch, range 64 (15-bit raster index) and 96 (17-bit: the 16x16 PUs leave the single-dword
+    keys): squares identical to x265amd_me_fullsearch, rectangles against the oracle on a sample of blocks, and a
+    subset of shapes gives the same planes as the full set."""
+    from x265_amd import synth
+    W, H, F = 448, 320, 2
+    for R in (64, 96):
+        seq = synth.make_sequence(W, H, F + 2, search_range=24, seed=60 + R)
+        seq[2, 100:180, 120:260] = 33
+        seq[1, 60:220, 80:300] = 33
+        fr = dev(seq)
+        cur = fr[2:]
+        refs = torch.stack([fr[1:-1], fr[:-2]], dim=1)    # [F][2][H][W]
+        got = gpu.me_fullsearch_pu_all(cur, refs, R)
+        for b in (64, 32, 16):
+            want = gpu.me_fullsearch(cur, refs, b, R, method="brute")
+            assert torch.equal(got[(b, b)].reshape(want.shape), want), (R, b)
+        for (bw, bh) in gpu.PU_SHAPES:
+            if bw == bh and bw > 8:
+                continue
+            nb = (W // bw) * (H // bh)
+            step = max(1, nb // 24)
+            for fi, ri in ((0, 0), (1, 1)):
+                c, r = seq[2 + fi], seq[2 + fi - 1 - ri]
+                want = oracle.me_fullsearch_wh(c, r, bw, bh, R, first=fi, step=step, nthreads=16).reshape(-1)
+                idx = np.arange(fi, nb, step)
+                g = gpu.mv_to_numpy(got[(bw, bh)])[fi, ri].reshape(-1)
+                np.testing.assert_array_equal(g[idx], want[idx], f"R{R} {bw}x{bh} f{fi} r{ri}")
+        sub = gpu.me_fullsearch_pu_all(cur, refs, R, shapes=((8, 8), (64, 32)))
+        assert list(sub) == [(8, 8), (64, 32)]
+        assert torch.equal(sub[(8, 8)], got[(8, 8)]) and torch.equal(sub[(64, 32)], got[(64, 32)])
+
+
 @pytest.mark.parametrize("R", [0, 1, 3, 7, 13, 33])
 def test_me_odd_and_degenerate_ranges_vs_oracle(gpu, oracle, R):
     """Search ranges that are not multiples of the 4-wide candidate groups, down to a single candidate, on a

@@ -97,3 +97,19 @@ def test_tq_frame_random(oracle, reference):
             np.testing.assert_array_equal(lvl, l1)
             np.testing.assert_array_equal(sums, s1)
             np.testing.assert_array_equal(rec, r1)
+
+
+@pytest.mark.parametrize("bw,bh", [(64, 32), (32, 64), (32, 16), (16, 32), (16, 8), (8, 16), (8, 8), (16, 16)])
+def test_me_rectangular_blocks(oracle, reference, bw, bh):
+    """The search over w x h blocks (the inter PU shapes): the restatement against the reference's own
+    xSadN[log2(w) - 2](h, ..) (src/pixel.cpp:30-101) on a small picture where every block meets a border."""
+    rng = np.random.default_rng(bw * 100 + bh)
+    ref = rng.integers(0, 256, (64, 128), dtype=np.uint8)
+    cur = np.roll(ref, (3, -5), axis=(0, 1)).copy()
+    cur[20:30, 40:70] = 128                      # a flat patch ...
+    ref[10:40, 30:90] = 128                      # ... inside a flat area: ties, the first one must win
+    a = oracle.me_fullsearch_wh(cur, ref, bw, bh, 9, nthreads=4)
+    b = reference.me_fullsearch_wh(cur, ref, bw, bh, 9, nthreads=4)
+    np.testing.assert_array_equal(a, b)
+    if bw == bh:
+        np.testing.assert_array_equal(a.reshape(-1), oracle.me_fullsearch(cur, ref, bw, 9, nthreads=4))

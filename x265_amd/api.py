@@ -71,6 +71,9 @@ SIGNATURES = {
     "x265amd_me_fullsearch_pu": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    "x265amd_me_fullsearch_pu_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int64, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_void_p),
+                                               C.c_void_p]),
     "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -299,6 +302,34 @@ def me_fullsearch_pu(cur, ref, search_range=64, sizes=(64, 32, 16)):
     _check(_lib().x265amd_me_fullsearch_pu(cp, ref.data_ptr(), w, h, cs, search_range, f, cfs,
                                            ref.stride(0) if f > 1 else 0, nrefs, ref.stride(1) if nrefs > 1 else 0,
                                            ptr(64), ptr(32), ptr(16), _stream()), "x265amd_me_fullsearch_pu")
+    return out
+
+
+# include/x265_amd.h: enum x265amd_pu_shape, (width, height) in that order
+PU_SHAPES = ((64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8), (8, 16), (8, 8))
+
+
+def me_fullsearch_pu_all(cur, ref, search_range=64, shapes=PU_SHAPES):
+    """Every inter PU shape of every CTU in one pass (x265amd_me_fullsearch_pu_all): square 64 .. 8 and the 2NxN /
+    Nx2N rectangles.  cur / ref as for me_fullsearch.  Returns {(w, h): int32 [F][R][H / h][W / w][2]}: the
+    exhaustive search of the w x h blocks tiling the picture, each under its own legality."""
+    cp, f, h, w, cs, cfs = _planes(cur, torch.uint8, "cur")
+    _dev(ref, torch.uint8, "ref")
+    if ref.dim() == 2:
+        ref = ref.unsqueeze(0)
+    if ref.dim() == 3:
+        ref = ref.unsqueeze(1)
+    if ref.dim() != 4 or ref.shape[0] != f or ref.shape[2:] != (h, w) or ref.stride(3) != 1 or ref.stride(2) != cs:
+        raise ValueError("ref: need [F][R][H][W] with the row stride of cur")
+    nrefs = ref.shape[1]
+    shapes = tuple(tuple(s) for s in shapes)
+    if not shapes or any(s not in PU_SHAPES for s in shapes):
+        raise ValueError(f"shapes: some of {PU_SHAPES}")
+    out = {s: torch.empty((f, nrefs, h // s[1], w // s[0], 2), dtype=torch.int32, device=cur.device) for s in shapes}
+    ptrs = (C.c_void_p * len(PU_SHAPES))(*[out[s].data_ptr() if s in out else None for s in PU_SHAPES])
+    _check(_lib().x265amd_me_fullsearch_pu_all(cp, ref.data_ptr(), w, h, cs, search_range, f, cfs,
+                                               ref.stride(0) if f > 1 else 0, nrefs, ref.stride(1) if nrefs > 1 else 0,
+                                               ptrs, _stream()), "x265amd_me_fullsearch_pu_all")
     return out
 
 

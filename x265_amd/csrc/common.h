@@ -56,6 +56,7 @@ int cu_count();
 // and, in me_sea.hip, the address of the static scratch array on that device
 int me_kernels_device_setup(DeviceState &ds);
 int me_tree_device_setup(DeviceState &ds);
+int me_pu_device_setup(DeviceState &ds);
 int me_sea_device_setup(DeviceState &ds);
 
 // dynamic-LDS opt-in of one kernel: the device limit minus the kernel's own static LDS

@@ -63,6 +63,7 @@ extern "C" int x265amd_init(int device)
     // once per device, with that device current: LDS opt-ins and the scratch array's address
     int st = me_kernels_device_setup(ds);
     if (st == X265AMD_OK) st = me_tree_device_setup(ds);
+    if (st == X265AMD_OK) st = me_pu_device_setup(ds);
     if (st == X265AMD_OK) st = me_sea_device_setup(ds);
     if (st != X265AMD_OK) return st;
     ds.init = true;
