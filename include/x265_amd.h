@@ -209,6 +209,32 @@ int x265amd_me_fullsearch_pu_all(const uint8_t *d_cur, const uint8_t *d_ref, int
                                  int range, int nframes, int64_t cur_frame_stride, int64_t ref_frame_stride,
                                  int nrefs, int64_t ref_ref_stride, x265amd_mv *const *d_out, void *stream);
 
+/* ------------------------------------------------------- intra decision */
+
+/* The luma intra mode decision of `ncus` independent CUs (first slice): for each CU the 35
+ * predictions of xEncIntraPredLuma (src/encode.cpp:1617-1652 over xPredIntraPlanar :1353, xPredIntraDc :1418,
+ * xPredIntraAng :1446), their SADs against the source block (xSadN, src/pixel.cpp:30-101) and the cost / argmin of
+ * src/encode.cpp:725-765: cost = SAD + lambda * (1 for the first most probable mode, 2 for the other two, 3
+ * otherwise; the reference sets lambda = QP, :597), first strict minimum in mode order from MAX_SAD.
+ *   d_src, src_stride, width, height: the luma plane; d_xy[2 * i], d_xy[2 * i + 1]: top-left corner of CU i (a CU that
+ *     does not lie inside the plane gets {0xffffffff, 0xffffffff} and nothing else is written for it)
+ *   size: 4, 8, 16 or 32 (MAX_CU_SIZE, inc/config.h:38)
+ *   d_ref + i * ref_stride: the 4 * size + 1 reference samples of CU i as xEncIntraLoadRef (src/encode.cpp:1163-1256)
+ *     leaves them in pucPixRef[0] after padding -- left column from the bottom up, the corner, the row above; the
+ *     [1 2 1] smoothing (:1260-1265) is applied here
+ *   d_mpm + 3 * i: ucMostModeY of CU i (src/encode.cpp:1268-1293)
+ *   d_best[i]: winner and its cost; d_sads (may be NULL): [ncus][35] plain SADs; d_pred (may be NULL):
+ *     [ncus][size * size] the winner's prediction (what src/encode.cpp:867 regenerates for the residual).
+ * In the encoder the CUs of one launch are those of one anti-diagonal: their neighbours are reconstructed. */
+typedef struct x265amd_intra_best {
+    uint32_t mode;
+    uint32_t cost;
+} x265amd_intra_best;
+int x265amd_intra_decide_luma(const uint8_t *d_src, int src_stride, int width, int height, const int32_t *d_xy,
+                              int ncus, int size, const uint8_t *d_ref, int ref_stride, const uint8_t *d_mpm,
+                              uint32_t lambda, x265amd_intra_best *d_best, uint32_t *d_sads, uint8_t *d_pred,
+                              void *stream);
+
 /* -------------------------------------------------------- transform/quant */
 
 /* One descriptor for the three TQ entry points.  Planes are batched over

@@ -195,6 +195,45 @@ class Oracle(_Lib):
         return rec
 
 
+    # ---- intra luma (src/encode.cpp:725-765, 1260-1265, 1617-1652) ----
+    def intra_filter(self, ref0):
+        n = (ref0.size - 1) // 4
+        ref1 = np.zeros_like(ref0)
+        self.lib.orc_intra_filter(_p(_chk(ref0, np.uint8), _u8p), _p(ref1, _u8p), n)
+        return ref1
+
+    def intra_pred_luma(self, ref0, ref1, n, mode):
+        dst = np.zeros((n, n), np.uint8)
+        self.lib.orc_intra_pred_luma(_p(_chk(ref0, np.uint8), _u8p), _p(_chk(ref1, np.uint8), _u8p), n, mode,
+                                     _p(dst, _u8p), n)
+        return dst
+
+    def intra_decide_luma(self, src, ref0, mpm, lam):
+        """src: uint8[n][n]; ref0: uint8[4n+1]; mpm: uint8[3].  Returns (sads[35], best_mode, best_cost, best_pred)."""
+        n = src.shape[0]
+        sads = np.zeros(35, np.uint32)
+        bm, bc = C.c_uint32(), C.c_uint32()
+        pred = np.zeros((n, n), np.uint8)
+        self.lib.orc_intra_decide_luma(_p(_chk(src, np.uint8), _u8p), n, _p(_chk(ref0, np.uint8), _u8p),
+                                       _p(_chk(mpm, np.uint8), _u8p), C.c_uint32(lam), n,
+                                       sads.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(bm), C.byref(bc),
+                                       _p(pred, _u8p))
+        return sads, bm.value, bc.value, pred
+
+
+# oracle/ref_shim.cpp: struct ref_intra_rec (MAX_CU_SIZE = 32, inc/config.h:38)
+INTRA_REC_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("ref0", "u1", 129), ("ref1", "u1", 129), ("mpm", "u1", 3),
+                            ("best_mode", "u1"), ("sad", "<u4", 35), ("pred_fnv", "<u4", 35)], align=True)
+
+
+def fnv1a(block):
+    """FNV-1a over the bytes of a uint8 block in raster order (the hash ref_shim.cpp records per prediction)."""
+    h = 2166136261
+    for b in np.ascontiguousarray(block).reshape(-1).tolist():
+        h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+    return h
+
+
 class Reference(_Lib):
     """The real reference, compiled from /root/reference by `make -C oracle ref`."""
 
@@ -248,6 +287,26 @@ class Reference(_Lib):
         if n < 0:
             raise ValueError("reference rejects this geometry (src/params.cpp:73-77)")
         return rec, nbytes, md5, bs[:n].copy()
+
+
+    def intra_pred_luma(self, ref0, ref1, n, mode):
+        """The reference's xEncIntraPredLuma on caller-supplied sample arrays (4n+1 bytes each)."""
+        dst = np.zeros((n, n), np.uint8)
+        self.lib.ref_intra_pred_luma(_p(_chk(ref0, np.uint8), _u8p), _p(_chk(ref1, np.uint8), _u8p), n, mode,
+                                     _p(dst, _u8p))
+        return dst
+
+    def intra_record(self, yuv, w, h, cu, qp, frame=0):
+        """Run the reference's encoder over frames 0 .. frame and record the luma decisions of `frame` from inside
+        its loop.  Returns INTRA_REC_DTYPE[ncus]."""
+        cap = (w // cu) * (h // cu)
+        out = np.zeros(cap, INTRA_REC_DTYPE)
+        assert INTRA_REC_DTYPE.itemsize == 552, INTRA_REC_DTYPE.itemsize
+        n = self.lib.ref_intra_record(_p(_chk(yuv, np.uint8), _u8p), w, h, cu, qp, frame,
+                                      C.c_void_p(out.ctypes.data), cap)
+        if n < 0:
+            raise ValueError("reference rejects this geometry")
+        return out[:n]
 
 
 def have_reference():

@@ -251,4 +251,106 @@ int ref_encode_intra(const uint8_t *yuv, int w, int h, int cu, int qp, int nfram
     return bs_pos;
 }
 
+/* ---- intra luma: the reference's own prediction, and a recording of its own mode decisions ---- */
+
+static X265_t g_ih; /* a handle whose cache the prediction entry points read and write */
+
+/* xEncIntraPredLuma (src/encode.cpp:1617) on a caller's sample arrays: ref0 = pucPixRef[0], ref1 = pucPixRef[1]
+ * (4 * size + 1 bytes each).  dst: size x size, stride size. */
+void ref_intra_pred_luma(const uint8_t *ref0, const uint8_t *ref1, int size, int mode, uint8_t *dst)
+{
+    memcpy(g_ih.cache.pucPixRef[0], ref0, 4 * size + 1);
+    memcpy(g_ih.cache.pucPixRef[1], ref1, 4 * size + 1);
+    xEncIntraPredLuma(&g_ih, (UInt)mode, (UInt)size);
+    for (int i = 0; i < size; i++) memcpy(dst + i * size, g_ih.cache.pucPredY + i * MAX_CU_SIZE, size);
+}
+
+/* One record per CU of the recorded frame, filled from INSIDE the reference's encode loop: the luma-size entry
+ * of xSadN[] is pointed at a wrapper that calls the reference's function and, when the call is one of the 35 of
+ * the luma decision (src/encode.cpp:756: source = the CU cache, candidate = pucPredY), notes what the encoder
+ * had in its cache at that moment. */
+struct ref_intra_rec {
+    int32_t x, y;
+    uint8_t ref0[4 * MAX_CU_SIZE + 1]; /* pucPixRef[0] after xEncIntraLoadRef */
+    uint8_t ref1[4 * MAX_CU_SIZE + 1]; /* pucPixRef[1] */
+    uint8_t mpm[3];                    /* ucMostModeY */
+    uint8_t best_mode;                 /* nBestModeY as stored at src/encode.cpp:864 */
+    uint32_t sad[35];                  /* what xSadN returned for each mode */
+    uint32_t pred_fnv[35];             /* FNV-1a of each mode's size x size prediction */
+};
+static X265_t *g_rec_h;
+static ref_intra_rec *g_rec;
+static int g_rec_cap, g_rec_n, g_rec_calls, g_rec_on, g_rec_size;
+static xSad *g_rec_orig;
+
+static UInt32 rec_sad(const UInt N, const UInt8 *pSrc, const UInt ss, const UInt8 *pRef, const UInt sr)
+{
+    const UInt32 v = g_rec_orig(N, pSrc, ss, pRef, sr);
+    X265_Cache *c = &g_rec_h->cache;
+    if (g_rec_on && pSrc == c->pucPixY && pRef == c->pucPredY) {
+        const int mode = g_rec_calls % 35, cu = g_rec_calls / 35;
+        if (mode == 0) {
+            if (cu > 0 && cu - 1 < g_rec_cap) g_rec[cu - 1].best_mode = c->nBestModeY; /* the CU before this one */
+            if (cu < g_rec_cap) {
+                ref_intra_rec *r = &g_rec[cu];
+                r->x = (int32_t)g_rec_h->uiCUX;
+                r->y = (int32_t)g_rec_h->uiCUY;
+                memcpy(r->ref0, c->pucPixRef[0], sizeof r->ref0);
+                memcpy(r->ref1, c->pucPixRef[1], sizeof r->ref1);
+                memcpy(r->mpm, c->ucMostModeY, 3);
+            }
+            g_rec_n = cu + 1;
+        }
+        if (cu < g_rec_cap) {
+            uint32_t hsh = 2166136261u;
+            for (int i = 0; i < g_rec_size; i++)
+                for (int j = 0; j < g_rec_size; j++) hsh = (hsh ^ pRef[i * sr + j]) * 16777619u;
+            g_rec[cu].sad[mode] = v;
+            g_rec[cu].pred_fnv[mode] = hsh;
+        }
+        g_rec_calls++;
+    }
+    return v;
+}
+
+/* Encode frames 0 .. frame of yuv like ref_encode_intra and record the luma decisions of frame `frame`.
+ * Returns the number of CUs recorded (<= cap), -1 for a geometry the reference rejects. */
+int ref_intra_record(const uint8_t *yuv, int w, int h, int cu, int qp, int frame, ref_intra_rec *out, int cap)
+{
+    static X265_t hnd;
+    xDefaultParams(&hnd);
+    hnd.usWidth = (UInt16)w;
+    hnd.usHeight = (UInt16)h;
+    hnd.ucMaxCUWidth = (UInt8)cu;
+    hnd.iQP = qp;
+    hnd.eSliceType = SLICE_I;
+    if (w % cu || h % cu || cu < 16 || cu > MAX_CU_SIZE || w > MAX_WIDTH) return -1;
+    xCheckParams(&hnd);
+    xEncInit(&hnd);
+    const size_t fsz = (size_t)w * h * 3 / 2;
+    UInt8 *buf = (UInt8 *)malloc(fsz + 65536);
+    const int slot = xLog2(cu - 1) - 2;
+    g_rec_h = &hnd;
+    g_rec = out;
+    g_rec_cap = cap;
+    g_rec_n = g_rec_calls = 0;
+    g_rec_size = cu;
+    g_rec_orig = xSadN[slot];
+    xSadN[slot] = rec_sad;
+    for (int f = 0; f <= frame; f++) {
+        X265_Frame fr;
+        fr.pucY = (UInt8 *)yuv + f * fsz;
+        fr.pucU = fr.pucY + (size_t)w * h;
+        fr.pucV = fr.pucU + (size_t)w * h / 4;
+        g_rec_on = f == frame;
+        xEncEncode(&hnd, &fr, buf, (UInt32)(fsz + 65536));
+    }
+    xSadN[slot] = g_rec_orig;
+    g_rec_on = 0;
+    if (g_rec_n > 0 && g_rec_n - 1 < cap) out[g_rec_n - 1].best_mode = hnd.cache.nBestModeY; /* the last CU */
+    free(buf);
+    xEncFree(&hnd);
+    return g_rec_n < cap ? g_rec_n : cap;
+}
+
 } /* extern "C" */

@@ -421,3 +421,147 @@ void orc_tq_inverse(const int16_t *level, int cstride, const uint8_t *pred, int 
         }
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* Intra luma prediction and the 35-mode decision.     */
+/* ref[4n + 1] is the reference's sample array (src/encode.cpp:1193):        */
+/* ref[0 .. 2n-1] the left column from the bottom up (ref[2n-1] beside row   */
+/* 0), ref[2n] the corner, ref[2n+1 .. 4n] the row above, left to right.     */
+/* ------------------------------------------------------------------------ */
+/* src/table.cpp:32-39 (which modes read the smoothed samples), :49-56, :59-66 */
+static const uint8_t kIntraFilter[5][35] = {
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1},
+    {1, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1},
+    {1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+static const int8_t kIntraAngle[35] = {0,   0,   32,  26,  21,  17,  13,  9,  5,  2,  0,  -2, -5, -9, -13, -17, -21, -26,
+                                       -32, -26, -21, -17, -13, -9,  -5,  -2, 0,  2,  5,  9,  13, 17, 21,  26,  32};
+static const int16_t kIntraInvAngle[35] = {0,   0,   256, 315, 390, 482, 630, 910, 1638, 4096, 0,   4096, 1638, 910, 630, 482, 390, 315,
+                                           256, 315, 390, 482, 630, 910, 1638, 4096, 0,  4096, 1638, 910, 630, 482, 390, 315, 256};
+
+/* the [1 2 1] smoothing of the sample array, ends kept (src/encode.cpp:1260-1265) */
+void orc_intra_filter(const uint8_t *ref0, uint8_t *ref1, int n)
+{
+    ref1[0] = ref0[0];
+    ref1[4 * n] = ref0[4 * n];
+    for (int i = 1; i < 4 * n; i++) ref1[i] = (uint8_t)((ref0[i - 1] + 2 * ref0[i] + ref0[i + 1] + 2) >> 2);
+}
+
+static void intra_planar(const uint8_t *ref, uint8_t *dst, int ds, int n) /* src/encode.cpp:1353-1396 */
+{
+    const int lg = log2n(n);
+    const uint8_t *left = ref + 2 * n - 1, *top = ref + 2 * n + 1;
+    int16_t lc[65], tr[65], br[65], rc[65];
+    for (int i = 0; i <= n; i++) {
+        tr[i] = top[i];
+        lc[i] = left[-i];
+    }
+    const int bl = left[-n], trt = top[n];
+    for (int i = 0; i < n; i++) {
+        br[i] = (int16_t)(bl - tr[i]);
+        rc[i] = (int16_t)(trt - lc[i]);
+        tr[i] = (int16_t)(tr[i] << lg);
+        lc[i] = (int16_t)(lc[i] << lg);
+    }
+    for (int i = 0; i < n; i++) {
+        int16_t hp = (int16_t)(lc[i] + n);
+        for (int j = 0; j < n; j++) {
+            hp = (int16_t)(hp + rc[i]);
+            tr[j] = (int16_t)(tr[j] + br[j]);
+            dst[i * ds + j] = (uint8_t)((hp + tr[j]) >> (lg + 1));
+        }
+    }
+}
+
+static void intra_dc(const uint8_t *ref, uint8_t *dst, int ds, int n) /* src/encode.cpp:1398-1444, luma */
+{
+    const uint8_t *left = ref + 2 * n - 1, *top = ref + 2 * n + 1;
+    uint32_t st = 0, sl = 0;
+    for (int i = 0; i < n; i++) {
+        st += top[i];
+        sl += left[-i];
+    }
+    const uint8_t dc = (uint8_t)((st + sl + n) / (2 * n));
+    for (int i = 0; i < n; i++) memset(dst + i * ds, dc, n);
+    dst[0] = (uint8_t)((top[0] + left[0] + 2 * dst[0] + 2) >> 2);
+    for (int i = 1; i < n; i++) {
+        dst[i] = (uint8_t)((top[i] + 3 * dst[i] + 2) >> 2);
+        dst[i * ds] = (uint8_t)((left[-i] + 3 * dst[i * ds] + 2) >> 2);
+    }
+}
+
+static void intra_ang(const uint8_t *ref, uint8_t *dst, int ds, int n, int mode) /* src/encode.cpp:1446-1534, luma */
+{
+    const int hor = mode < 18, ang = kIntraAngle[mode], inv = kIntraInvAngle[mode];
+    const uint8_t *tl = ref + 2 * n;
+    uint8_t buf[2 * 64 + 1 + 64];
+    uint8_t *rm = buf + (ang < 0 ? 64 : 0);
+    for (int x = 0; x <= n; x++) rm[x] = hor ? tl[-x] : tl[x];
+    if (ang < 0) {
+        int sum = 128;
+        for (int x = -1; x > ((n * ang) >> 5); x--) {
+            sum += inv;
+            rm[x] = tl[hor ? (sum >> 8) : -(sum >> 8)];
+        }
+    } else {
+        for (int x = n + 1; x <= 2 * n; x++) rm[x] = hor ? tl[-x] : tl[x];
+    }
+    int pos = 0;
+    for (int k = 0; k < n; k++) {
+        pos += ang;
+        const int idx = pos >> 5, fact = pos & 31;
+        for (int x = 0; x < n; x++)
+            dst[k * ds + x] = fact ? (uint8_t)(((32 - fact) * rm[x + idx + 1] + fact * rm[x + idx + 2] + 16) >> 5) : rm[x + idx + 1];
+    }
+    if (ang == 0) {
+        const int o = hor ? 1 : -1;
+        for (int x = 0; x < n; x++) {
+            int v = dst[x * ds] + ((tl[(x + 1) * o] - tl[0]) >> 1);
+            dst[x * ds] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    }
+    if (hor)
+        for (int k = 0; k < n - 1; k++)
+            for (int x = k + 1; x < n; x++) {
+                uint8_t t = dst[k * ds + x];
+                dst[k * ds + x] = dst[x * ds + k];
+                dst[x * ds + k] = t;
+            }
+}
+
+/* xEncIntraPredLuma (src/encode.cpp:1617-1652): ref0 = the samples, ref1 = smoothed */
+void orc_intra_pred_luma(const uint8_t *ref0, const uint8_t *ref1, int n, int mode, uint8_t *dst, int ds)
+{
+    const uint8_t *ref = kIntraFilter[log2n(n) - 2][mode] ? ref1 : ref0;
+    if (mode == 0)
+        intra_planar(ref, dst, ds, n);
+    else if (mode == 1)
+        intra_dc(ref, dst, ds, n);
+    else
+        intra_ang(ref, dst, ds, n, mode);
+}
+
+/* The luma mode decision of one CU (src/encode.cpp:725-765): cost = SAD + lambda * (1 for the first most
+ * probable mode, 2 for the other two, 3 otherwise), first strict minimum in mode order.  sads[35] receives
+ * the plain SADs, best_pred (n*n, stride n; may be NULL) the winner's prediction. */
+void orc_intra_decide_luma(const uint8_t *src, int ss, const uint8_t *ref0, const uint8_t *mpm, uint32_t lambda,
+                           int n, uint32_t *sads, uint32_t *best_mode, uint32_t *best_cost, uint8_t *best_pred)
+{
+    uint8_t ref1[4 * 64 + 1], pred[64 * 64];
+    orc_intra_filter(ref0, ref1, n);
+    uint32_t best = ORC_MAX_SAD, bm = 0;
+    for (int m = 0; m < 35; m++) {
+        orc_intra_pred_luma(ref0, ref1, n, m, pred, n);
+        const uint32_t sad = orc_sad(n, n, src, ss, pred, n);
+        const uint32_t cost = sad + lambda * (m == mpm[0] ? 1u : (m == mpm[1] || m == mpm[2]) ? 2u : 3u);
+        if (sads) sads[m] = sad;
+        if (cost < best) {
+            best = cost;
+            bm = (uint32_t)m;
+        }
+    }
+    *best_mode = bm;
+    *best_cost = best;
+    if (best_pred) orc_intra_pred_luma(ref0, ref1, n, (int)bm, best_pred, n);
+}

@@ -90,6 +90,22 @@ void orc_tq_inverse(const int16_t *level, int cstride, const uint8_t *pred, int 
                     const orc_mv *mv, int mv_ctu, int width, int height, int n, int qp,
                     int slice_type, const uint8_t *modes, uint8_t *rec, int rstride, int nthreads);
 
+/* The same search for bw x bh blocks tiling the picture (the inter PU shapes): xSadN[log2(bw) - 2](bh, ..),
+ * src/pixel.cpp:30-101.  out[(by0 / bh) * (width / bw) + bx0 / bw]. */
+void orc_me_fullsearch_wh(const uint8_t *cur, const uint8_t *ref, int width, int height, int stride,
+                          int bw, int bh, int range, orc_mv *out, int first, int step, int count,
+                          int nthreads);
+
+/* ---- intra luma prediction and mode decision ----
+ * ref0[4n + 1]: the CU's reference samples as xEncIntraLoadRef leaves them in pucPixRef[0] after padding
+ * (src/encode.cpp:1193-1256): left column bottom-up, corner, row above. */
+void orc_intra_filter(const uint8_t *ref0, uint8_t *ref1, int n);                     /* src/encode.cpp:1260-1265 */
+void orc_intra_pred_luma(const uint8_t *ref0, const uint8_t *ref1, int n, int mode,  /* src/encode.cpp:1617-1652 */
+                         uint8_t *dst, int ds);
+void orc_intra_decide_luma(const uint8_t *src, int ss, const uint8_t *ref0, const uint8_t *mpm, uint32_t lambda,
+                           int n, uint32_t *sads, uint32_t *best_mode, uint32_t *best_cost,
+                           uint8_t *best_pred);                                       /* src/encode.cpp:725-765 */
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,6 +219,34 @@ def gen_intra_cfg1(ref):
     print("intra_cfg1.json:", doc["recon_md5"][0], "...", doc["recon_md5"][-1])
 
 
+def gen_intra_decide(ref):
+    """The reference's own luma mode decisions, recorded from inside xEncEncode (oracle/ref_shim.cpp
+    ref_intra_record: the luma entry of xSadN[] is wrapped): per CU the padded reference samples, their smoothed
+    copy, the most probable modes, the SAD and an FNV-1a hash of the prediction of each of the 35 modes and the
+    mode the encoder kept.  Two encodes: BASELINE.json configs[0] (416x240, CU 16, QP 32; frames 0 and 5) and a
+    CU-32 probe (416x224, QP 27, frame 1).  The source frames are synth.make_intra_probe's and are not stored."""
+    out, meta = {}, []
+    for (w, h, cu, qp, frames) in ((416, 240, 16, 32, (0, 5)), (416, 224, 32, 27, (1,))):
+        yuv = synth.make_intra_probe(w, h, max(frames) + 1)
+        for fr in frames:
+            rec = ref.intra_record(yuv, w, h, cu, qp, fr)
+            assert len(rec) == (w // cu) * (h // cu)
+            k = f"w{w}h{h}cu{cu}qp{qp}f{fr}"
+            nref = 4 * cu + 1
+            out[k + "_xy"] = np.stack([rec["x"], rec["y"]], axis=1).astype(np.int32)
+            out[k + "_ref0"] = np.ascontiguousarray(rec["ref0"][:, :nref])
+            out[k + "_ref1"] = np.ascontiguousarray(rec["ref1"][:, :nref])
+            out[k + "_mpm"] = np.ascontiguousarray(rec["mpm"])
+            out[k + "_best"] = np.ascontiguousarray(rec["best_mode"])
+            out[k + "_sad"] = np.ascontiguousarray(rec["sad"]).astype(np.uint32)
+            out[k + "_fnv"] = np.ascontiguousarray(rec["pred_fnv"]).astype(np.uint32)
+            meta.append(dict(key=k, width=w, height=h, cu=cu, qp=qp, frame=fr, ncus=int(len(rec)),
+                             input_md5=hashlib.md5(yuv[fr].tobytes()).hexdigest()))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "intra_decide.npz"), **out)
+    print("intra_decide.npz:", [m["key"] for m in meta])
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.Reference()
@@ -226,6 +254,7 @@ def main():
     gen_me(ref)
     gen_tq_frame(ref)
     gen_intra_cfg1(ref)
+    gen_intra_decide(ref)
 
 
 if __name__ == "__main__":

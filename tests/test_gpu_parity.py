@@ -559,3 +559,61 @@ def test_me_odd_and_degenerate_ranges_vs_oracle(gpu, oracle, R):
     tree = gpu.me_fullsearch_pu(cur, ref, R)
     np.testing.assert_array_equal(gpu.mv_to_numpy(tree[64])[0, 0], want)
     np.testing.assert_array_equal(gpu.mv_to_numpy(tree[16])[0, 0], oracle.me_fullsearch(seq[1], seq[0], 16, R, nthreads=8))
+
+
+# ------------------------------------------------------ intra decision --
+def test_intra_decide_luma_recorded_reference_decisions(gpu):
+    """x265amd_intra_decide_luma against the reference encoder's own decisions (tests/golden/intra_decide.npz,
+    recorded from inside xEncEncode: BASELINE.json configs[0] frames 0 and 5 at CU 16, a CU-32 probe): every CU of
+    the frame in one launch -- the 35 SADs, the mode kept, its cost, and the winner's prediction by its hash."""
+    from conftest import load_golden
+    from oracle.pyoracle import fnv1a
+    from x265_amd import synth
+    z, meta = load_golden("intra_decide.npz")
+    for m in meta:
+        k, n, lam = m["key"], m["cu"], m["qp"]
+        yuv = synth.make_intra_probe(m["width"], m["height"], m["frame"] + 1)
+        Y = yuv[m["frame"], :m["width"] * m["height"]].reshape(m["height"], m["width"])
+        best, sads, pred = gpu.intra_decide_luma(dev(Y), dev(z[k + "_xy"]), n, dev(z[k + "_ref0"]), dev(z[k + "_mpm"]), lam,
+                                                 want_sads=True, want_pred=True)
+        best, sads, pred = host(best), host(sads), host(pred)
+        np.testing.assert_array_equal(sads.astype(np.uint32), z[k + "_sad"], k)
+        np.testing.assert_array_equal(best[:, 0], z[k + "_best"].astype(np.int32), k)
+        mpm = z[k + "_mpm"]
+        bm = best[:, 0]
+        w = np.where(bm == mpm[:, 0], 1, np.where((bm == mpm[:, 1]) | (bm == mpm[:, 2]), 2, 3))
+        np.testing.assert_array_equal(best[:, 1], sads[np.arange(len(bm)), bm] + w * lam)
+        for i in range(0, len(bm), 3):
+            assert fnv1a(pred[i]) == z[k + "_fnv"][i, bm[i]], (k, i)
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_intra_decide_luma_vs_oracle_random(gpu, oracle, n):
+    """All four sizes on random inputs: noise / ramps / extreme samples, random most probable modes (repeats
+    included), lambda 0 .. 51, CUs anywhere in the plane, one CU outside it (refused in its slot)."""
+    rng = np.random.default_rng(900 + n)
+    W, H, ncu = 160, 96, 48
+    Y = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    Y[:, 80:] = (np.add.outer(np.arange(H), np.arange(80)) // 2 % 256).astype(np.uint8)
+    xy = np.stack([rng.integers(0, W - n + 1, ncu), rng.integers(0, H - n + 1, ncu)], axis=1).astype(np.int32)
+    xy[5] = (W - n + 1, 0)                                   # does not fit
+    ref = rng.integers(0, 256, (ncu, 4 * n + 8), dtype=np.uint8)
+    ref[::3] = np.clip(np.cumsum(rng.integers(-2, 3, ref[::3].shape), axis=1) + 120, 0, 255)
+    ref[1::7] = rng.choice(np.array([0, 255], np.uint8), ref[1::7].shape)
+    mpm = rng.integers(0, 35, (ncu, 3)).astype(np.uint8)
+    mpm[::5, 1] = mpm[::5, 0]
+    for lam in (0, 32, 51):
+        best, sads, pred = gpu.intra_decide_luma(dev(Y), dev(xy), n, dev(ref), dev(mpm), lam, want_sads=True, want_pred=True)
+        best, sads, pred = host(best), host(sads), host(pred)
+        for i in range(ncu):
+            if i == 5:
+                assert best[i, 0] == -1 and best[i, 1] == -1
+                continue
+            x, y = xy[i]
+            os_, obm, obc, opred = oracle.intra_decide_luma(np.ascontiguousarray(Y[y:y + n, x:x + n]),
+                                                           np.ascontiguousarray(ref[i, :4 * n + 1]), np.ascontiguousarray(mpm[i]), lam)
+            np.testing.assert_array_equal(sads[i].astype(np.uint32), os_, f"n {n} CU {i}")
+            assert (best[i, 0], best[i, 1]) == (obm, obc), (n, i)
+            np.testing.assert_array_equal(pred[i], opred)
+    only_best, none_s, none_p = gpu.intra_decide_luma(dev(Y), dev(xy), n, dev(ref), dev(mpm), 51)
+    assert none_s is None and none_p is None and np.array_equal(host(only_best), best)

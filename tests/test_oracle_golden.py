@@ -137,3 +137,36 @@ def test_intra_cfg1_live(reference):
     assert [int(x) for x in nbytes] == doc["bytes_per_frame"]
     assert hashlib.md5(bs.tobytes()).hexdigest() == doc["bitstream_md5"]
     assert [bytes(m).hex() for m in md5] == doc["recon_md5"]
+
+
+def test_intra_decide_recorded_from_the_reference(oracle):
+    """tests/golden/intra_decide.npz holds the reference encoder's OWN luma decisions, recorded from inside
+    xEncEncode on BASELINE.json configs[0] (frames 0 and 5) and on a CU-32 probe: per CU the reference samples,
+    their smoothed copy, the most probable modes, the SAD and a hash of the prediction of each of the 35 modes,
+    and the mode kept.  The restatement must reproduce all of it from (source, samples, most probable modes)."""
+    from oracle.pyoracle import fnv1a
+    from x265_amd import synth
+    z, meta = load_golden("intra_decide.npz")
+    for m in meta:
+        k, n = m["key"], m["cu"]
+        yuv = synth.make_intra_probe(m["width"], m["height"], m["frame"] + 1)
+        assert hashlib.md5(yuv[m["frame"]].tobytes()).hexdigest() == m["input_md5"]
+        Y = yuv[m["frame"], :m["width"] * m["height"]].reshape(m["height"], m["width"])
+        xy, ref0, ref1, mpm = z[k + "_xy"], z[k + "_ref0"], z[k + "_ref1"], z[k + "_mpm"]
+        assert len(xy) == m["ncus"] == (m["width"] // n) * (m["height"] // n)
+        lam = m["qp"]                                        # src/encode.cpp:597
+        for i in range(m["ncus"]):
+            x, y = int(xy[i, 0]), int(xy[i, 1])
+            src = np.ascontiguousarray(Y[y:y + n, x:x + n])
+            r0 = np.ascontiguousarray(ref0[i])
+            r1 = oracle.intra_filter(r0)
+            np.testing.assert_array_equal(r1, ref1[i], f"{k} CU {i}: smoothed samples")
+            sads, bm, bc, pred = oracle.intra_decide_luma(src, r0, np.ascontiguousarray(mpm[i]), lam)
+            np.testing.assert_array_equal(sads, z[k + "_sad"][i], f"{k} CU {i}: SADs")
+            assert bm == z[k + "_best"][i], (k, i)
+            w = 1 if bm == mpm[i, 0] else 2 if bm in (mpm[i, 1], mpm[i, 2]) else 3
+            assert bc == sads[bm] + w * lam
+            if i % 7 == 0:                                   # every mode's prediction, on a sample of the CUs
+                for mode in range(35):
+                    assert fnv1a(oracle.intra_pred_luma(r0, r1, n, mode)) == z[k + "_fnv"][i, mode], (k, i, mode)
+            assert fnv1a(pred) == z[k + "_fnv"][i, bm]

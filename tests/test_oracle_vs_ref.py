@@ -113,3 +113,37 @@ def test_me_rectangular_blocks(oracle, reference, bw, bh):
     np.testing.assert_array_equal(a, b)
     if bw == bh:
         np.testing.assert_array_equal(a.reshape(-1), oracle.me_fullsearch(cur, ref, bw, 9, nthreads=4))
+
+
+@pytest.mark.parametrize("n", [4, 8, 16, 32])
+def test_intra_prediction_random_samples(oracle, reference, n):
+    """xEncIntraPredLuma itself (src/encode.cpp:1617) on random sample arrays, all 35 modes, all four sizes
+    (the encoder only ever runs CU 16 and 32; the prediction code takes any size): smooth ramps, noise, extremes."""
+    rng = np.random.default_rng(500 + n)
+    for it in range(40):
+        kind = it % 4
+        if kind == 0:
+            r0 = rng.integers(0, 256, 4 * n + 1, dtype=np.uint8)
+        elif kind == 1:
+            r0 = np.clip(np.cumsum(rng.integers(-3, 4, 4 * n + 1)) + 128, 0, 255).astype(np.uint8)
+        elif kind == 2:
+            r0 = rng.choice(np.array([0, 255], np.uint8), 4 * n + 1)
+        else:
+            r0 = np.full(4 * n + 1, rng.integers(0, 256), np.uint8)
+        r1 = oracle.intra_filter(r0)
+        for mode in range(35):
+            np.testing.assert_array_equal(oracle.intra_pred_luma(r0, r1, n, mode), reference.intra_pred_luma(r0, r1, n, mode),
+                                          f"n {n} mode {mode} kind {kind}")
+
+
+def test_intra_record_matches_fixture(reference):
+    """The committed fixture is what the reference produces here and now (same probe, same recorder)."""
+    from conftest import load_golden
+    from x265_amd import synth
+    z, meta = load_golden("intra_decide.npz")
+    m = meta[0]
+    yuv = synth.make_intra_probe(m["width"], m["height"], m["frame"] + 1)
+    rec = reference.intra_record(yuv, m["width"], m["height"], m["cu"], m["qp"], m["frame"])
+    np.testing.assert_array_equal(rec["sad"], z[m["key"] + "_sad"])
+    np.testing.assert_array_equal(rec["best_mode"], z[m["key"] + "_best"])
+    np.testing.assert_array_equal(rec["pred_fnv"], z[m["key"] + "_fnv"])

@@ -30,3 +30,7 @@ print("PU 64 + 32 + 16, one pass     %6.2f ms  %6.0f Mpix/s" % (dt * 1e3, 1920 *
 t2, dt = timed(lambda: x265_amd.me_fullsearch_pu(fr[1:], fr[:-1], R, sizes=(32, 16)))
 print("PU 32 + 16, one pass          %6.2f ms  %6.0f Mpix/s" % (dt * 1e3, 1920 * 1080 * NF / dt / 1e6))
 print("identical to the per-size kernels:", all(torch.equal(tree[b], res[b]) for b in (64, 32, 16)))
+allpu, dt = timed(lambda: x265_amd.me_fullsearch_pu_all(fr[1:], fr[:-1], R))
+print("all ten PU shapes (169 PUs per CTU), one pass %6.2f ms  %6.0f Mpix/s" % (dt * 1e3, 1920 * 1080 * NF / dt / 1e6))
+print("squares identical to the per-size kernels:",
+      all(torch.equal(allpu[(b, b)].reshape(res[b].shape), res[b]) for b in (64, 32, 16)))

@@ -74,6 +74,9 @@ SIGNATURES = {
     "x265amd_me_fullsearch_pu_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_int64, C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_void_p),
                                                C.c_void_p]),
+    "x265amd_intra_decide_luma": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
     "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -331,6 +334,33 @@ def me_fullsearch_pu_all(cur, ref, search_range=64, shapes=PU_SHAPES):
                                                ref.stride(0) if f > 1 else 0, nrefs, ref.stride(1) if nrefs > 1 else 0,
                                                ptrs, _stream()), "x265amd_me_fullsearch_pu_all")
     return out
+
+
+def intra_decide_luma(src, xy, size, ref, mpm, lam, want_sads=False, want_pred=False):
+    """The 35-mode luma intra decision of a batch of independent CUs (x265amd_intra_decide_luma).
+    src: uint8 [H][W] plane; xy: int32 [n][2] (x, y) corners; ref: uint8 [n][>= 4 size + 1] padded reference
+    samples (pucPixRef[0]); mpm: uint8 [n][3]; lam: lambda (the reference uses QP).
+    Returns (best int32 [n][2] = (mode, cost), sads int32 [n][35] or None, pred uint8 [n][size][size] or None)."""
+    _dev(src, torch.uint8, "src")
+    _dev(xy, torch.int32, "xy")
+    _dev(ref, torch.uint8, "ref")
+    _dev(mpm, torch.uint8, "mpm")
+    if src.dim() != 2 or src.stride(1) != 1:
+        raise ValueError("src: need a [H][W] plane with unit pixel stride")
+    n = xy.shape[0]
+    if xy.shape != (n, 2) or not xy.is_contiguous() or mpm.shape != (n, 3) or not mpm.is_contiguous():
+        raise ValueError("xy: contiguous [n][2]; mpm: contiguous [n][3]")
+    if ref.dim() != 2 or ref.shape[0] != n or ref.stride(1) != 1 or ref.shape[1] < 4 * size + 1:
+        raise ValueError("ref: need [n][>= 4 * size + 1]")
+    best = torch.empty((n, 2), dtype=torch.int32, device=src.device)
+    sads = torch.empty((n, 35), dtype=torch.int32, device=src.device) if want_sads else None
+    pred = torch.empty((n, size, size), dtype=torch.uint8, device=src.device) if want_pred else None
+    _check(_lib().x265amd_intra_decide_luma(src.data_ptr(), src.stride(0), src.shape[1], src.shape[0], xy.data_ptr(), n,
+                                            size, ref.data_ptr(), ref.stride(0) if n > 1 else max(ref.shape[1], 4 * size + 1),
+                                            mpm.data_ptr(), lam, best.data_ptr(),
+                                            sads.data_ptr() if want_sads else None, pred.data_ptr() if want_pred else None,
+                                            _stream()), "x265amd_intra_decide_luma")
+    return best, sads, pred
 
 
 def mv_to_numpy(mv):
