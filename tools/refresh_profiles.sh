@@ -1,24 +1,44 @@
 #!/bin/bash
-# Everything profiles/ holds, in one gpurun call: bench lines of every workload, rocprofv3 kernel stats of the
-# default bench, PMC traffic.  Each GPU step under its own time limit; stops at the first failure.
+# Everything profiles/ holds for a round, from the GPU box (through gpurun), in parts so that each call stays well
+# inside gpurun's limit:  tools/refresh_profiles.sh bench | trace | pmc | sq
+# Results under gpurun_out/prof/; tools/collect_profiles.py copies the summaries into profiles/ afterwards.
+# Each GPU step runs under its own time limit; the script stops at the first failure.
 set -e
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/final
+OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd $ROOT
-timeout -k 10 400 python bench.py > $OUT/bench_1080p.json 2> $OUT/bench_1080p.err
-echo "1080p done"
-timeout -k 10 300 python bench.py --workload 4k --no-cpu-baseline > $OUT/bench_4k.json 2> $OUT/bench_4k.err
-echo "4k done"
-timeout -k 10 300 python bench.py --workload 8k4ref --no-cpu-baseline > $OUT/bench_8k4ref.json 2> $OUT/bench_8k4ref.err
-echo "8k done"
-timeout -k 10 300 python bench.py --workload tq1080p --tu 32 > $OUT/bench_tq1080p.json 2> $OUT/bench_tq.err
-timeout -k 10 300 python bench.py --workload gop1080p > $OUT/bench_gop1080p.json 2> $OUT/bench_gop.err
-echo "tq, gop done"
-cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace --output-format csv -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
-echo "trace done"
-cd $ROOT
-bash tools/run_pmc.sh 1080p 3 1 > $OUT/pmc.log 2>&1
-cp $ROOT/gpurun_out/pmc_1080p/pmc_traffic.json $OUT/pmc_traffic.json
-echo "pmc done"
+case "$1" in
+bench)
+  timeout -k 10 500 python bench.py > $OUT/bench_1080p.json 2> $OUT/bench_1080p.err; echo "1080p done"
+  for WL in 4k 8k4ref gop1080p; do
+    timeout -k 10 300 python bench.py --workload $WL --no-cpu-baseline > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; echo "$WL done"
+  done
+  for TU in 32 16 8 4; do
+    timeout -k 10 200 python bench.py --workload tq1080p --tu $TU --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_tq1080p_tu$TU.json 2> $OUT/bench_tq_tu$TU.err
+  done
+  echo "tq done"
+  timeout -k 10 200 python tools/pu_bench.py > $OUT/pu_bench.txt 2>&1; echo "pu done"
+  ;;
+trace)
+  cd /tmp && export TMPDIR=/tmp
+  for WL in 1080p 4k 8k4ref gop1080p tq1080p; do
+    timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL --output-format csv -- python3 $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace_$WL.log 2>&1
+    echo "trace $WL done"
+  done
+  ;;
+pmc)
+  export PMC_JSON=$OUT/pmc_traffic.json
+  for WL in 1080p 4k 8k4ref gop1080p tq1080p; do
+    bash tools/run_pmc.sh $WL 3 1 $WL > $OUT/pmc_$WL.log 2>&1; echo "pmc $WL done"
+  done
+  for TU in 16 8 4; do
+    bash tools/run_pmc.sh tq1080p 3 1 tq1080p_tu$TU --tu $TU > $OUT/pmc_tq_tu$TU.log 2>&1; echo "pmc tq tu$TU done"
+  done
+  ;;
+sq)
+  bash tools/run_pmc_sq.sh 1080p 2 1 > $OUT/sq_1080p.log 2>&1; echo "sq 1080p done"
+  bash tools/run_pmc_tq.sh tq1080p 3 1 > $OUT/sq_tq.log 2>&1; echo "sq tq done"
+  ;;
+*) echo "usage: $0 bench|trace|pmc|sq"; exit 2;;
+esac
