@@ -235,6 +235,35 @@ int x265amd_intra_decide_luma(const uint8_t *d_src, int src_stride, int width, i
                               uint32_t lambda, x265amd_intra_best *d_best, uint32_t *d_sads, uint8_t *d_pred,
                               void *stream);
 
+/* One intra frame on the GPU: the pixel path of the reference's encode loop (src/encode.cpp:668-941 minus the
+ * entropy coder) -- reference samples from the reconstruction (xEncIntraLoadRef :1163), luma and chroma mode
+ * decisions (:725-853), prediction, xSubDct + xQuant, xDeQuant + xIDctAdd (:863-925), reconstruction written back
+ * as the next CUs' neighbours (:930-934).  CU = PU = TU as there; 4:2:0; cu = 16 or 32.  The CUs with the same
+ * cux + 2 * cuy do not depend on one another: a frame is x265amd_intra_waves() steps, each one prediction launch
+ * over that anti-diagonal's CUs plus the transform stage.  Outputs: the reconstruction (bit-exact with the
+ * reference's, i.e. its MD5 SEI), per-CU modes, and the quantised levels the entropy coder needs.
+ * All planes are device memory; strides in elements; the level planes have the strides of their pixel planes. */
+typedef struct x265amd_intra_frame {
+    int32_t width, height; /* luma size; multiples of cu */
+    int32_t cu;            /* 16 or 32 (src/params.cpp:76, MAX_CU_SIZE inc/config.h:38) */
+    int32_t qp;            /* also the lambda of the luma decision (src/encode.cpp:597); chroma uses g_aucChromaScale[qp] */
+    int32_t stride_y, stride_c;
+    const uint8_t *d_src_y, *d_src_u, *d_src_v;
+    uint8_t *d_rec_y, *d_rec_u, *d_rec_v;       /* OUT, and IN of later CUs */
+    uint8_t *d_pred_y, *d_pred_u, *d_pred_v;    /* OUT of the prediction stage, IN of the transform stage */
+    int16_t *d_level_y, *d_level_u, *d_level_v; /* OUT: quantised levels, picture geometry */
+    uint8_t *d_mode_y, *d_mode_c;               /* OUT [ncus]: luma mode, chroma mode (the real mode, not the index) */
+    uint32_t *d_cost_y, *d_cost_c;              /* optional OUT [ncus]: the winners' costs */
+    uint32_t *d_abs_sum_y, *d_abs_sum_u, *d_abs_sum_v; /* optional OUT [ncus]: xQuant's return values (the cbf) */
+} x265amd_intra_frame;
+/* number of anti-diagonals of the frame: width / cu + 2 * (height / cu - 1); -1 for a bad descriptor */
+int x265amd_intra_waves(const x265amd_intra_frame *frame);
+/* the prediction stage of one anti-diagonal (Stage 1b .. 2 and the prediction calls of Stage 3a): reads d_rec_*
+ * of earlier waves and d_mode_y of the left neighbours, writes d_pred_*, d_mode_*, d_cost_* of this wave's CUs */
+int x265amd_intra_predict_wave(const x265amd_intra_frame *frame, int wave, void *stream);
+/* the whole frame: for every wave, x265amd_intra_predict_wave, then x265amd_tq_roundtrip of the three planes */
+int x265amd_intra_encode_frame(const x265amd_intra_frame *frame, void *stream);
+
 /* -------------------------------------------------------- transform/quant */
 
 /* One descriptor for the three TQ entry points.  Planes are batched over

@@ -221,6 +221,18 @@ class Oracle(_Lib):
         return sads, bm.value, bc.value, pred
 
 
+    def intra_encode_frame(self, yuv, w, h, cu, qp, want_levels=False):
+        """yuv: uint8[w*h*3/2] (one frame).  Returns (rec uint8[w*h*3/2], mode_y uint8[ncus], mode_c uint8[ncus],
+        levels int16[w*h*3/2] or None): the pixel path of the reference's intra encode loop."""
+        n = (w // cu) * (h // cu)
+        rec = np.zeros_like(yuv)
+        my, mc = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        lv = np.zeros(yuv.size, np.int16) if want_levels else None
+        self.lib.orc_intra_encode_frame(_p(_chk(yuv, np.uint8), _u8p), w, h, cu, qp, _p(rec, _u8p), _p(my, _u8p),
+                                        _p(mc, _u8p), _p(lv, _i16p))
+        return rec, my, mc, lv
+
+
 # oracle/ref_shim.cpp: struct ref_intra_rec (MAX_CU_SIZE = 32, inc/config.h:38)
 INTRA_REC_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("ref0", "u1", 129), ("ref1", "u1", 129), ("mpm", "u1", 3),
                             ("best_mode", "u1"), ("sad", "<u4", 35), ("pred_fnv", "<u4", 35)], align=True)

@@ -491,7 +491,7 @@ static void intra_dc(const uint8_t *ref, uint8_t *dst, int ds, int n) /* src/enc
     }
 }
 
-static void intra_ang(const uint8_t *ref, uint8_t *dst, int ds, int n, int mode) /* src/encode.cpp:1446-1534, luma */
+static void intra_ang(const uint8_t *ref, uint8_t *dst, int ds, int n, int mode, int luma) /* src/encode.cpp:1446-1534 */
 {
     const int hor = mode < 18, ang = kIntraAngle[mode], inv = kIntraInvAngle[mode];
     const uint8_t *tl = ref + 2 * n;
@@ -514,7 +514,7 @@ static void intra_ang(const uint8_t *ref, uint8_t *dst, int ds, int n, int mode)
         for (int x = 0; x < n; x++)
             dst[k * ds + x] = fact ? (uint8_t)(((32 - fact) * rm[x + idx + 1] + fact * rm[x + idx + 2] + 16) >> 5) : rm[x + idx + 1];
     }
-    if (ang == 0) {
+    if (luma && ang == 0) {
         const int o = hor ? 1 : -1;
         for (int x = 0; x < n; x++) {
             int v = dst[x * ds] + ((tl[(x + 1) * o] - tl[0]) >> 1);
@@ -539,7 +539,7 @@ void orc_intra_pred_luma(const uint8_t *ref0, const uint8_t *ref1, int n, int mo
     else if (mode == 1)
         intra_dc(ref, dst, ds, n);
     else
-        intra_ang(ref, dst, ds, n, mode);
+        intra_ang(ref, dst, ds, n, mode, 1);
 }
 
 /* The luma mode decision of one CU (src/encode.cpp:725-765): cost = SAD + lambda * (1 for the first most
@@ -564,4 +564,132 @@ void orc_intra_decide_luma(const uint8_t *src, int ss, const uint8_t *ref0, cons
     *best_mode = bm;
     *best_cost = best;
     if (best_pred) orc_intra_pred_luma(ref0, ref1, n, (int)bm, best_pred, n);
+}
+
+/* ------------------------------------------------------------------------ */
+/* One intra frame: the pixel path of the encode loop (src/encode.cpp:668-941 */
+/* without the entropy coder), CU = PU = TU, 4:2:0.                           */
+/* ------------------------------------------------------------------------ */
+/* xEncIntraLoadRef + xPaddingRef (src/encode.cpp:1133-1266) read from the reconstructed planes instead of the
+ * line buffers (same pixels: the buffers hold the row above and the column to the left of the CU). */
+static void intra_load_ref(const uint8_t *rec, int stride, int x0, int y0, int n, int bL, int bT, int bTR, uint8_t *ref)
+{
+    const int valid[5] = {0, bL, bL && bT, bT, bTR};
+    const int off[6] = {0, n, 2 * n, 2 * n + 1, 3 * n + 1, 4 * n + 1};
+    if (!(bL || bT || bTR)) {
+        memset(ref, 0x80, 4 * n + 1);
+        return;
+    }
+    if (bL)
+        for (int i = 0; i < n; i++) ref[n + i] = rec[(size_t)(y0 + n - 1 - i) * stride + x0 - 1];
+    if (bL && bT) ref[2 * n] = rec[(size_t)(y0 - 1) * stride + x0 - 1];
+    if (bT)
+        for (int i = 0; i < n; i++) ref[2 * n + 1 + i] = rec[(size_t)(y0 - 1) * stride + x0 + i];
+    if (bTR)
+        for (int i = 0; i < n; i++) ref[3 * n + 1 + i] = rec[(size_t)(y0 - 1) * stride + x0 + n + i];
+    int b = 0;
+    while (!valid[b]) b++;
+    for (int i = 0; i < off[b]; i++) ref[i] = ref[off[b]];
+    for (; b < 5; b++)
+        if (!valid[b])
+            for (int i = off[b]; i < off[b + 1]; i++) ref[i] = ref[off[b] - 1];
+}
+
+static void intra_pred_chroma(const uint8_t *ref, int n, int mode, uint8_t *dst) /* src/encode.cpp:1654-1706 */
+{
+    if (mode == 0)
+        intra_planar(ref, dst, n, n);
+    else if (mode == 1) {
+        const uint8_t *left = ref + 2 * n - 1, *top = ref + 2 * n + 1;
+        uint32_t s = 0;
+        for (int i = 0; i < n; i++) s += top[i] + left[-i];
+        memset(dst, (int)((s + n) / (2 * n)), (size_t)n * n);
+    } else {
+        intra_ang(ref, dst, n, n, mode, 0); /* bLuma FALSE: no gradient filter on the zero-angle modes */
+    }
+}
+
+/* yuv: one frame, planes Y (w x h), U, V (w/2 x h/2), strides = widths.  rec: the same layout.  mode_y, mode_c:
+ * per CU in raster order (mode_c = the real chroma mode).  levels (may be NULL): int16, same layout as yuv. */
+void orc_intra_encode_frame(const uint8_t *yuv, int w, int h, int cu, int qp, uint8_t *rec, uint8_t *mode_y,
+                            uint8_t *mode_c, int16_t *levels)
+{
+    const int wc = w / 2, hc = h / 2, nc = cu / 2, ncx = w / cu, ncy = h / cu;
+    const uint8_t *sy = yuv, *su = yuv + (size_t)w * h, *sv = su + (size_t)wc * hc;
+    uint8_t *ry = rec, *ru = rec + (size_t)w * h, *rv = ru + (size_t)wc * hc;
+    const int qpc = orc_chroma_qp(qp);
+    int16_t t0[32 * 32], t1[32 * 32], q[32 * 32];
+    uint8_t s32[32 * 32], p32[32 * 32], r32[32 * 32];
+    for (int cy = 0; cy < ncy; cy++)
+        for (int cx = 0; cx < ncx; cx++) {
+            const int x0 = cx * cu, y0 = cy * cu, idx = cy * ncx + cx;
+            const int bL = cx > 0, bT = cy > 0, bTR = bT && cx + 1 < ncx;
+            uint8_t ref0[129], refu[65], refv[65], mpm[3], pred[32 * 32], predu[16 * 16], predv[16 * 16];
+            intra_load_ref(ry, w, x0, y0, cu, bL, bT, bTR, ref0);
+            intra_load_ref(ru, wc, x0 / 2, y0 / 2, nc, bL, bT, bTR, refu);
+            intra_load_ref(rv, wc, x0 / 2, y0 / 2, nc, bL, bT, bTR, refv);
+            /* most probable modes, src/encode.cpp:1268-1293 (the mode above is DC there: `bT && uiY`, uiY == 0) */
+            const int left = bL ? mode_y[idx - 1] : 1, top = 1;
+            if (left == top) {
+                if (left > 1)
+                    mpm[0] = (uint8_t)left, mpm[1] = (uint8_t)(((left + 29) % 32) + 2), mpm[2] = (uint8_t)(((left - 1) % 32) + 2);
+                else
+                    mpm[0] = 0, mpm[1] = 1, mpm[2] = 26;
+            } else {
+                mpm[0] = (uint8_t)left, mpm[1] = (uint8_t)top;
+                mpm[2] = (left != 0 && top != 0) ? 0 : (left + top) < 2 ? 26 : 1;
+            }
+            uint32_t bm, bc;
+            orc_intra_decide_luma(sy + (size_t)y0 * w + x0, w, ref0, mpm, (uint32_t)qp, cu, NULL, &bm, &bc, pred);
+            mode_y[idx] = (uint8_t)bm;
+            /* chroma: src/encode.cpp:781-853 */
+            int cand[6] = {0, 26, 10, 1, -1, (int)bm};
+            for (int i = 0; i < 4; i++)
+                if (cand[i] == (int)bm) {
+                    cand[i] = 34;
+                    break;
+                }
+            uint32_t bestc = ORC_MAX_SAD;
+            int bk = 0;
+            for (int k = 0; k < 6; k++) {
+                if (k == 4) continue; /* LM_CHROMA is skipped */
+                intra_pred_chroma(refu, nc, cand[k], predu);
+                intra_pred_chroma(refv, nc, cand[k], predv);
+                const uint32_t s = orc_sad(nc, nc, su + (size_t)(y0 / 2) * wc + x0 / 2, wc, predu, nc) +
+                                   orc_sad(nc, nc, sv + (size_t)(y0 / 2) * wc + x0 / 2, wc, predv, nc);
+                if (s < bestc) {
+                    bestc = s;
+                    bk = k;
+                }
+            }
+            const int mc = cand[bk];
+            mode_c[idx] = (uint8_t)mc;
+            intra_pred_chroma(refu, nc, mc, predu);
+            intra_pred_chroma(refv, nc, mc, predv);
+            /* transform stage, src/encode.cpp:863-925, per plane */
+            for (int pl = 0; pl < 3; pl++) {
+                const int n = pl ? nc : cu, st = pl ? wc : w, px = pl ? x0 / 2 : x0, py = pl ? y0 / 2 : y0;
+                const uint8_t *src = pl == 0 ? sy : pl == 1 ? su : sv;
+                uint8_t *dst = pl == 0 ? ry : pl == 1 ? ru : rv;
+                const uint8_t *pp = pl == 0 ? pred : pl == 1 ? predu : predv;
+                for (int i = 0; i < n; i++) {
+                    memcpy(s32 + i * 32, src + (size_t)(py + i) * st + px, n);
+                    memcpy(p32 + i * 32, pp + i * n, n);
+                }
+                const unsigned mode = pl ? (unsigned)mc : bm;
+                orc_sub_dct(t0, s32, p32, 32, t0, t1, n, n, mode);
+                const uint32_t sum = orc_quant(q, t0, 32, (unsigned)(pl ? qpc : qp), n, n, ORC_SLICE_I);
+                if (sum) {
+                    orc_dequant(t0, q, 32, (unsigned)(pl ? qpc : qp), n, n, ORC_SLICE_I);
+                    orc_idct_add(r32, t0, p32, 32, t1, t0, n, n, mode);
+                } else {
+                    for (int i = 0; i < n; i++) memcpy(r32 + i * 32, p32 + i * 32, n);
+                }
+                for (int i = 0; i < n; i++) memcpy(dst + (size_t)(py + i) * st + px, r32 + i * 32, n);
+                if (levels) {
+                    int16_t *lv = levels + (pl == 0 ? 0 : pl == 1 ? (size_t)w * h : (size_t)w * h + (size_t)wc * hc);
+                    for (int i = 0; i < n; i++) memcpy(lv + (size_t)(py + i) * st + px, q + i * 32, (size_t)n * 2);
+                }
+            }
+        }
 }

@@ -106,6 +106,11 @@ void orc_intra_decide_luma(const uint8_t *src, int ss, const uint8_t *ref0, cons
                            int n, uint32_t *sads, uint32_t *best_mode, uint32_t *best_cost,
                            uint8_t *best_pred);                                       /* src/encode.cpp:725-765 */
 
+/* One intra frame, the pixel path of the encode loop (src/encode.cpp:668-941 without the entropy coder):
+ * yuv / rec: planes Y, U, V back to back (strides = widths); mode_y / mode_c per CU; levels may be NULL. */
+void orc_intra_encode_frame(const uint8_t *yuv, int w, int h, int cu, int qp, uint8_t *rec, uint8_t *mode_y,
+                            uint8_t *mode_c, int16_t *levels);
+
 #ifdef __cplusplus
 }
 #endif

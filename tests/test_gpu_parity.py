@@ -617,3 +617,65 @@ def test_intra_decide_luma_vs_oracle_random(gpu, oracle, n):
             np.testing.assert_array_equal(pred[i], opred)
     only_best, none_s, none_p = gpu.intra_decide_luma(dev(Y), dev(xy), n, dev(ref), dev(mpm), 51)
     assert none_s is None and none_p is None and np.array_equal(host(only_best), best)
+
+
+# ---------------------------------------------------------- intra frame --
+def _planes_of(yuv, w, h):
+    y = yuv[:w * h].reshape(h, w)
+    u = yuv[w * h:w * h + w * h // 4].reshape(h // 2, w // 2)
+    v = yuv[w * h + w * h // 4:].reshape(h // 2, w // 2)
+    return y, u, v
+
+
+def test_intra_frame_cfg1_reconstruction_md5(gpu, oracle):
+    """BASELINE.json configs[0] on the GPU: x265amd_intra_encode_frame (neighbour samples from the reconstruction,
+    luma + chroma decisions, prediction, xSubDct / xQuant / xDeQuant / xIDctAdd, anti-diagonal by anti-diagonal)
+    reconstructs every one of the 8 frames to the bytes whose MD5 the reference encoder printed
+    (tests/golden/intra_cfg1.json), with the luma modes recorded from inside the reference on frames 0 and 5 and
+    the levels / chroma modes of the oracle's restatement."""
+    import hashlib, json, os
+    from conftest import GOLDEN, load_golden
+    from x265_amd import synth
+    with open(os.path.join(GOLDEN, "intra_cfg1.json")) as f:
+        doc = json.load(f)
+    z, meta = load_golden("intra_decide.npz")
+    w, h, cu, qp = doc["width"], doc["height"], doc["cu"], doc["qp"]
+    yuv = synth.make_intra_probe(w, h, doc["frames"])
+    for fr in range(doc["frames"]):
+        y, u, v = _planes_of(yuv[fr], w, h)
+        o = gpu.intra_encode_frame(dev(y), dev(u), dev(v), cu, qp, wave_by_wave=(fr == 3))
+        rec = np.concatenate([host(o["rec_y"]).ravel(), host(o["rec_u"]).ravel(), host(o["rec_v"]).ravel()])
+        assert hashlib.md5(rec.tobytes()).hexdigest() == doc["recon_md5"][fr], fr
+        for m in meta:
+            if (m["width"], m["height"], m["cu"], m["qp"], m["frame"]) == (w, h, cu, qp, fr):
+                np.testing.assert_array_equal(host(o["mode_y"]), z[m["key"] + "_best"])
+        if fr in (0, 7):
+            orec, my, mc, lv = oracle.intra_encode_frame(yuv[fr], w, h, cu, qp, want_levels=True)
+            np.testing.assert_array_equal(host(o["mode_y"]), my)
+            np.testing.assert_array_equal(host(o["mode_c"]), mc)
+            lvl = np.concatenate([host(o["level_y"]).ravel(), host(o["level_u"]).ravel(), host(o["level_v"]).ravel()])
+            np.testing.assert_array_equal(lvl, lv)
+
+
+@pytest.mark.parametrize("w,h,cu,qp", [(416, 224, 32, 27), (128, 96, 32, 12), (96, 64, 16, 45), (32, 32, 32, 30), (16, 48, 16, 22)])
+def test_intra_frame_vs_oracle(gpu, oracle, w, h, cu, qp):
+    """Other sizes (CU 32, a single CU, a single column), quantisers and content against the oracle's restatement
+    of the loop: reconstruction, modes, levels, xQuant sums."""
+    from x265_amd import synth
+    rng = np.random.default_rng(w + h + cu + qp)
+    frames = [synth.make_intra_probe(w, h, 2)[1] if w % 2 == 0 else None,
+              rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8),
+              np.full(w * h * 3 // 2, 77, np.uint8)]
+    for yuv in frames:
+        y, u, v = _planes_of(yuv, w, h)
+        o = gpu.intra_encode_frame(dev(y), dev(u), dev(v), cu, qp)
+        orec, my, mc, lv = oracle.intra_encode_frame(yuv, w, h, cu, qp, want_levels=True)
+        rec = np.concatenate([host(o["rec_y"]).ravel(), host(o["rec_u"]).ravel(), host(o["rec_v"]).ravel()])
+        np.testing.assert_array_equal(host(o["mode_y"]), my)
+        np.testing.assert_array_equal(host(o["mode_c"]), mc)
+        lvl = np.concatenate([host(o["level_y"]).ravel(), host(o["level_u"]).ravel(), host(o["level_v"]).ravel()])
+        np.testing.assert_array_equal(lvl, lv)
+        np.testing.assert_array_equal(rec, orec)
+        ncx = w // cu
+        sums = np.abs(lv[:w * h].reshape(h // cu, cu, ncx, cu).astype(np.int64)).sum(axis=(1, 3)).ravel()
+        np.testing.assert_array_equal(host(o["abs_sum_y"]).astype(np.int64), sums)

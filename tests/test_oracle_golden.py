@@ -170,3 +170,21 @@ def test_intra_decide_recorded_from_the_reference(oracle):
                 for mode in range(35):
                     assert fnv1a(oracle.intra_pred_luma(r0, r1, n, mode)) == z[k + "_fnv"][i, mode], (k, i, mode)
             assert fnv1a(pred) == z[k + "_fnv"][i, bm]
+
+
+def test_intra_frame_restatement_reproduces_cfg1_md5(oracle):
+    """BASELINE.json configs[0] without the reference: the restated pixel path of the intra encode loop
+    (orc_intra_encode_frame: neighbour samples, luma and chroma decisions, transform stage, reconstruction) gives,
+    frame by frame, the reconstruction whose MD5 the reference printed (tests/golden/intra_cfg1.json), and on
+    frames 0 and 5 the luma modes recorded from inside the reference (intra_decide.npz)."""
+    from x265_amd import synth
+    with open(os.path.join(GOLDEN, "intra_cfg1.json")) as f:
+        doc = json.load(f)
+    z, meta = load_golden("intra_decide.npz")
+    yuv = synth.make_intra_probe(doc["width"], doc["height"], doc["frames"])
+    for fr in range(doc["frames"]):
+        rec, my, mc, _ = oracle.intra_encode_frame(yuv[fr], doc["width"], doc["height"], doc["cu"], doc["qp"])
+        assert hashlib.md5(rec.tobytes()).hexdigest() == doc["recon_md5"][fr], fr
+        for m in meta:
+            if (m["width"], m["height"], m["cu"], m["qp"], m["frame"]) == (doc["width"], doc["height"], doc["cu"], doc["qp"], fr):
+                np.testing.assert_array_equal(my, z[m["key"] + "_best"])

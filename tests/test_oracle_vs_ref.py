@@ -147,3 +147,19 @@ def test_intra_record_matches_fixture(reference):
     np.testing.assert_array_equal(rec["sad"], z[m["key"] + "_sad"])
     np.testing.assert_array_equal(rec["best_mode"], z[m["key"] + "_best"])
     np.testing.assert_array_equal(rec["pred_fnv"], z[m["key"] + "_fnv"])
+
+
+@pytest.mark.parametrize("w,h,cu,qp", [(128, 96, 32, 27), (96, 64, 16, 40), (64, 64, 32, 8)])
+def test_intra_frame_restatement_vs_reference_encoder(oracle, reference, w, h, cu, qp):
+    """The restated intra frame loop against the reference encoder's reconstruction on other content, sizes and
+    quantisers than the committed probe: textured noise, a flat frame (cbf zero almost everywhere: the copy branch), three
+    frames in a row (each intra frame stands alone)."""
+    rng = np.random.default_rng(w * 7 + cu + qp)
+    yuv = rng.integers(0, 256, (3, w * h * 3 // 2), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    yuv[1, :w * h] = ((xx * 3 + yy * 5) // 4 % 256 + rng.integers(0, 6, (h, w))).astype(np.uint8).ravel()
+    yuv[2] = 93
+    rec, nbytes, md5, bs = reference.encode_intra(yuv, w, h, cu, qp)
+    for fr in range(3):
+        orec, my, mc, lv = oracle.intra_encode_frame(yuv[fr], w, h, cu, qp, want_levels=True)
+        np.testing.assert_array_equal(orec, rec[fr], f"frame {fr}")

@@ -77,6 +77,9 @@ SIGNATURES = {
     "x265amd_intra_decide_luma": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                             C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
+    "x265amd_intra_waves": (C.c_int, [C.c_void_p]),
+    "x265amd_intra_predict_wave": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "x265amd_intra_encode_frame": (C.c_int, [C.c_void_p, C.c_void_p]),
     "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -361,6 +364,60 @@ def intra_decide_luma(src, xy, size, ref, mpm, lam, want_sads=False, want_pred=F
                                             sads.data_ptr() if want_sads else None, pred.data_ptr() if want_pred else None,
                                             _stream()), "x265amd_intra_decide_luma")
     return best, sads, pred
+
+
+class IntraFrame(C.Structure):
+    """include/x265_amd.h: x265amd_intra_frame"""
+    _fields_ = ([("width", C.c_int32), ("height", C.c_int32), ("cu", C.c_int32), ("qp", C.c_int32),
+                 ("stride_y", C.c_int32), ("stride_c", C.c_int32)] +
+                [(n, C.c_void_p) for n in ("d_src_y", "d_src_u", "d_src_v", "d_rec_y", "d_rec_u", "d_rec_v",
+                                           "d_pred_y", "d_pred_u", "d_pred_v", "d_level_y", "d_level_u", "d_level_v",
+                                           "d_mode_y", "d_mode_c", "d_cost_y", "d_cost_c",
+                                           "d_abs_sum_y", "d_abs_sum_u", "d_abs_sum_v")])
+
+
+def intra_encode_frame(y, u, v, cu, qp, wave_by_wave=False):
+    """One intra frame on the GPU (x265amd_intra_encode_frame): the pixel path of the reference's encode loop.
+    y: uint8 [H][W]; u, v: uint8 [H/2][W/2] (contiguous).  Returns a dict: rec_y / rec_u / rec_v, mode_y / mode_c
+    (uint8 [ncus]), cost_y / cost_c (int32 [ncus]), level_y / level_u / level_v (int16 planes), abs_sum_y / _u / _v.
+    wave_by_wave: drive the anti-diagonals from here (x265amd_intra_predict_wave + x265amd_tq_roundtrip per plane)
+    instead of the library's own loop -- the same launches."""
+    for t, n in ((y, "y"), (u, "u"), (v, "v")):
+        _dev(t, torch.uint8, n)
+        if t.dim() != 2 or not t.is_contiguous():
+            raise ValueError(f"{n}: need a contiguous [H][W] plane")
+    h, w = y.shape
+    if u.shape != (h // 2, w // 2) or v.shape != u.shape:
+        raise ValueError("u, v: need [H/2][W/2]")
+    ncus = (h // cu) * (w // cu) if cu in (16, 32) else 0
+    dv = y.device
+    o = {"rec_y": torch.zeros_like(y), "rec_u": torch.zeros_like(u), "rec_v": torch.zeros_like(v),
+         "pred_y": torch.zeros_like(y), "pred_u": torch.zeros_like(u), "pred_v": torch.zeros_like(v),
+         "level_y": torch.zeros((h, w), dtype=torch.int16, device=dv),
+         "level_u": torch.zeros((h // 2, w // 2), dtype=torch.int16, device=dv),
+         "level_v": torch.zeros((h // 2, w // 2), dtype=torch.int16, device=dv),
+         "mode_y": torch.zeros(ncus, dtype=torch.uint8, device=dv), "mode_c": torch.zeros(ncus, dtype=torch.uint8, device=dv),
+         "cost_y": torch.zeros(ncus, dtype=torch.int32, device=dv), "cost_c": torch.zeros(ncus, dtype=torch.int32, device=dv),
+         "abs_sum_y": torch.zeros(ncus, dtype=torch.int32, device=dv), "abs_sum_u": torch.zeros(ncus, dtype=torch.int32, device=dv),
+         "abs_sum_v": torch.zeros(ncus, dtype=torch.int32, device=dv)}
+    f = IntraFrame()
+    f.width, f.height, f.cu, f.qp, f.stride_y, f.stride_c = w, h, cu, qp, w, w // 2
+    f.d_src_y, f.d_src_u, f.d_src_v = y.data_ptr(), u.data_ptr(), v.data_ptr()
+    for k, t in o.items():
+        setattr(f, "d_" + k, t.data_ptr())
+    lib = _lib()
+    if not wave_by_wave:
+        _check(lib.x265amd_intra_encode_frame(C.byref(f), _stream()), "x265amd_intra_encode_frame")
+    else:
+        nw = lib.x265amd_intra_waves(C.byref(f))
+        if nw < 0:
+            raise X265AmdError("x265amd_intra_waves: bad frame descriptor")
+        for d in range(nw):
+            _check(lib.x265amd_intra_predict_wave(C.byref(f), d, _stream()), "x265amd_intra_predict_wave")
+            for pl, tu_, q_ in (("y", cu, qp), ("u", cu // 2, chroma_qp(qp)), ("v", cu // 2, chroma_qp(qp))):
+                tq_roundtrip({"y": y, "u": u, "v": v}[pl], o["pred_" + pl], tu_, q_, SLICE_I,
+                             out=(o["level_" + pl], o["abs_sum_" + pl], o["rec_" + pl]))
+    return o
 
 
 def mv_to_numpy(mv):

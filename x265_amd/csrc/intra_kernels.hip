@@ -29,8 +29,9 @@ __device__ const int16_t kIntraInvAngle[35] = {0,   0,   256, 315, 390, 482, 630
 
 constexpr int kMaxRef = 4 * 32 + 1;
 
-// pixel (r, c) of mode `mode`; ref = the sample array the mode reads (smoothed or not), dc = the DC value
-template <int N> __device__ __forceinline__ int intra_pixel(const uint8_t *ref, int mode, int r, int c, int dc)
+// pixel (r, c) of mode `mode`; ref = the sample array the mode reads (smoothed or not), dc = the DC value.
+// LUMA: the edge smoothing of DC and of the pure horizontal / vertical modes (bLuma of the reference's functions)
+template <int N, bool LUMA = true> __device__ __forceinline__ int intra_pixel(const uint8_t *ref, int mode, int r, int c, int dc)
 {
     constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
     const uint8_t *tl = ref + 2 * N;  // the corner; tl[1 + j] = above column j, tl[-1 - i] = left of row i
@@ -41,9 +42,9 @@ template <int N> __device__ __forceinline__ int intra_pixel(const uint8_t *ref, 
         return ((hp + tp) >> (L2 + 1)) & 0xff;
     }
     if (mode == 1) {  // DC with its edge smoothing (src/encode.cpp:1418-1444)
-        if (r == 0 && c == 0) return (tl[1] + tl[-1] + 2 * dc + 2) >> 2;
-        if (r == 0) return (tl[1 + c] + 3 * dc + 2) >> 2;
-        if (c == 0) return (tl[-1 - r] + 3 * dc + 2) >> 2;
+        if (LUMA && r == 0 && c == 0) return (tl[1] + tl[-1] + 2 * dc + 2) >> 2;
+        if (LUMA && r == 0) return (tl[1 + c] + 3 * dc + 2) >> 2;
+        if (LUMA && c == 0) return (tl[-1 - r] + 3 * dc + 2) >> 2;
         return dc;
     }
     // angular (src/encode.cpp:1446-1534): the main side is the left column for modes 2..17 (built as a row and
@@ -61,11 +62,56 @@ template <int N> __device__ __forceinline__ int intra_pixel(const uint8_t *ref, 
     const int idx = pos >> 5, fact = pos & 31;
     int p = main_ref(x + idx + 1);
     if (fact) p = ((32 - fact) * p + fact * main_ref(x + idx + 2) + 16) >> 5;
-    if (ang == 0 && x == 0) {  // modes 10 and 26: the first column / row follows the other side's gradient
+    if (LUMA && ang == 0 && x == 0) {  // modes 10 and 26: the first column / row follows the other side's gradient
         p += (tl[-sgn * (k + 1)] - tl[0]) >> 1;
         p = min(max(p, 0), 255);
     }
     return p;
+}
+
+// ---- pieces shared by the two kernels (one workgroup of 256 threads per CU) ----
+
+// the DC value of a sample array (src/encode.cpp:1398-1416), by wave 0; the caller puts a barrier after it
+template <int N> __device__ __forceinline__ void intra_dc_value(const uint8_t *ref, int lane, int *out)
+{
+    int s = 0;
+    for (int i = lane; i < 2 * N; i += 64) s += i < N ? ref[2 * N + 1 + i] : ref[2 * N - 1 - (i - N)];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) *out = (s + N) / (2 * N);
+}
+
+// SADs of the 35 luma modes (dealt round the four waves) into s_sad[]; s_ref = samples and smoothed samples, sp[] =
+// the lane's source pixels i = lane + 64 t.  The caller puts a barrier after it.
+template <int N, int PER>
+__device__ __forceinline__ void intra_luma_sads(const uint8_t (*s_ref)[kMaxRef + 3], const int (&sp)[PER], int dc, int wave, int lane,
+                                                uint32_t *s_sad)
+{
+    constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+    for (int mode = wave; mode < 35; mode += 4) {
+        const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][mode]];
+        uint32_t s = 0;
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+            const int i = lane + 64 * t;
+            if (i < N * N) s += (uint32_t)abs(sp[t] - intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc));
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) s_sad[mode] = s;
+    }
+}
+
+// cost and argmin exactly as src/encode.cpp:725-765: first strict minimum in mode order from MAX_SAD (one thread)
+__device__ __forceinline__ x265amd_intra_best intra_luma_argmin(const uint32_t *s_sad, int m0, int m1, int m2, uint32_t lambda)
+{
+    uint32_t bc = X265AMD_MAX_SAD, bm = 0;
+    for (int m = 0; m < 35; m++) {
+        const uint32_t cost = s_sad[m] + lambda * (m == m0 ? 1u : (m == m1 || m == m2) ? 2u : 3u);
+        if (cost < bc) {
+            bc = cost;
+            bm = (uint32_t)m;
+        }
+    }
+    return x265amd_intra_best{bm, bc};
 }
 
 template <int N>
@@ -97,12 +143,7 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(const uint8_t *__rest
         s_ref[1][i] = (i == 0 || i == 4 * N) ? (uint8_t)a : (uint8_t)((ref0[i - 1] + 2 * a + ref0[i + 1] + 2) >> 2);
     }
     __syncthreads();
-    if (wave == 0) {  // the DC value (src/encode.cpp:1398-1416): mode 1 reads the unsmoothed samples at every size
-        int s = 0;
-        for (int i = lane; i < 2 * N; i += 64) s += i < N ? s_ref[0][2 * N + 1 + i] : s_ref[0][2 * N - 1 - (i - N)];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) s_dc = (s + N) / (2 * N);
-    }
+    if (wave == 0) intra_dc_value<N>(s_ref[0], lane, &s_dc);  // mode 1 reads the unsmoothed samples at every size
     // the lane's pixels of the source CU: pixel i = lane + 64 t, raster order
     int sp[PER];
 #pragma unroll
@@ -112,35 +153,13 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(const uint8_t *__rest
     }
     __syncthreads();
     const int dc = s_dc;
-    for (int mode = wave; mode < 35; mode += 4) {
-        const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][mode]];
-        uint32_t s = 0;
-#pragma unroll
-        for (int t = 0; t < PER; t++) {
-            const int i = lane + 64 * t;
-            if (i < NPIX) {
-                const int p = intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc);
-                s += (uint32_t)abs(sp[t] - p);
-            }
-        }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) s_sad[mode] = s;
-    }
+    intra_luma_sads<N, PER>(s_ref, sp, dc, wave, lane, s_sad);
     __syncthreads();
     if (tid == 0) {
-        // cost and argmin exactly as src/encode.cpp:725-765: first strict minimum in mode order from MAX_SAD
         const uint8_t *mpm = mpms + 3 * (int64_t)cu;
-        const int m0 = mpm[0], m1 = mpm[1], m2 = mpm[2];
-        uint32_t bc = X265AMD_MAX_SAD, bm = 0;
-        for (int m = 0; m < 35; m++) {
-            const uint32_t cost = s_sad[m] + lambda * (m == m0 ? 1u : (m == m1 || m == m2) ? 2u : 3u);
-            if (cost < bc) {
-                bc = cost;
-                bm = (uint32_t)m;
-            }
-        }
-        best[cu] = x265amd_intra_best{bm, bc};
-        s_best = (int)bm;
+        const x265amd_intra_best b = intra_luma_argmin(s_sad, mpm[0], mpm[1], mpm[2], lambda);
+        best[cu] = b;
+        s_best = (int)b.mode;
     }
     if (sads && tid < 35) sads[35 * (int64_t)cu + tid] = s_sad[tid];
     if (pred) {  // workgroup-uniform
@@ -149,6 +168,179 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(const uint8_t *__rest
         const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][bm]];
         for (int i = tid; i < NPIX; i += 256)
             pred[(int64_t)cu * NPIX + i] = (uint8_t)intra_pixel<N>(ref, bm, i >> L2, i & (N - 1), dc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The prediction stage of the intra encoder for the CUs of ONE anti-diagonal of a frame (Stage 1b .. 2 of
+// src/encode.cpp:719-861 and the two prediction calls of Stage 3a, :867 and :876): reference samples from the
+// reconstruction written so far (xEncIntraLoadRef, :1163-1293, with xPaddingRef :1133), most probable modes, the
+// luma decision, the chroma decision over {planar, vertical, horizontal, DC, the luma mode} (:781-853; LM is
+// skipped there), and the winners' predictions into the prediction planes for the transform stage.
+//
+// Which neighbours exist follows from the position alone in this encoder (CU = PU = TU, raster order): left iff
+// x > 0, above iff y > 0, above-right iff y > 0 and the CU is not the last of its row, below-left never (the
+// line buffer of modes is reset per row and written for one CU height, :989-994, :1107-1111).  CU (x, y) needs
+// (x - 1, y), (x, y - 1) and (x + 1, y - 1): all CUs with the same x + 2 y are independent.
+// ---------------------------------------------------------------------------------------------
+struct IntraWave {
+    x265amd_intra_frame f;
+    int ncx, ncy;
+    int d;      // the anti-diagonal: CUs with cux + 2 cuy == d
+    int cy_lo;  // smallest cuy on it
+    uint32_t lambda;
+};
+
+// sample i of the reference array of an n x n block at (x0, y0) of plane `rec`: xEncIntraLoadRef + xPaddingRef
+__device__ __forceinline__ int intra_ref_sample(const uint8_t *rec, int stride, int x0, int y0, int n, int i, bool bL, bool bT, bool bTR)
+{
+    // blocks of the array: 0 below-left [0, n), 1 left [n, 2n), 2 corner {2n}, 3 above [2n+1, 3n+1), 4 above-right [3n+1, 4n+1)
+    const bool valid[5] = {false, bL, bL && bT, bT, bTR};
+    const int off[6] = {0, n, 2 * n, 2 * n + 1, 3 * n + 1, 4 * n + 1};
+    if (!(bL || bT || bTR)) return 0x80;  // :1203-1209
+    auto raw = [&](int j) -> int {  // sample j of a block that exists
+        if (j < 2 * n) return rec[(int64_t)(y0 + 2 * n - 1 - j) * stride + x0 - 1];  // the left column, bottom-up
+        if (j == 2 * n) return rec[(int64_t)(y0 - 1) * stride + x0 - 1];
+        return rec[(int64_t)(y0 - 1) * stride + x0 + (j - 2 * n - 1)];
+    };
+    const int b = i < n ? 0 : i < 2 * n ? 1 : i == 2 * n ? 2 : i < 3 * n + 1 ? 3 : 4;
+    if (valid[b]) return raw(i);
+    int first = 0;
+    while (!valid[first]) first++;
+    if (b < first) return raw(off[first]);  // everything before the first block that exists: its first sample
+    int m = b - 1;
+    while (!valid[m]) m--;                  // a gap after it: the last sample before the gap
+    return raw(off[m + 1] - 1);
+}
+
+template <int N>
+__global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
+{
+    constexpr int L2 = N == 16 ? 4 : 5;
+    constexpr int NC = N / 2, L2C = L2 - 1;
+    constexpr int NPIX = N * N, PER = NPIX / 64;
+    constexpr int NPIXC = NC * NC, PERC = NPIXC / 64;
+    const x265amd_intra_frame &f = w.f;
+    __shared__ uint8_t s_ref[2][kMaxRef + 3];
+    __shared__ uint8_t s_refc[2][4 * 16 + 4];  // U, V: chroma reads the samples as they are
+    __shared__ uint32_t s_sad[35], s_sadc[6];
+    __shared__ int s_dc, s_dcc[2], s_best, s_bestc, s_mpm[3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cuy = w.cy_lo + blockIdx.x, cux = w.d - 2 * cuy;
+    if (cux < 0 || cux >= w.ncx || cuy >= w.ncy) return;  // block-uniform (the host sizes the grid to fit)
+    const int x0 = cux * N, y0 = cuy * N, cu = cuy * w.ncx + cux;
+    const bool bL = cux > 0, bT = cuy > 0, bTR = bT && cux + 1 < w.ncx;
+
+    // ---- reference samples: luma, and its smoothed copy; U and V ----
+    if (tid <= 4 * N) s_ref[0][tid] = (uint8_t)intra_ref_sample(f.d_rec_y, f.stride_y, x0, y0, N, tid, bL, bT, bTR);
+    for (int i = tid; i < 2 * (4 * NC + 1); i += 256) {
+        const int pl = i >= 4 * NC + 1, j = i - pl * (4 * NC + 1);
+        s_refc[pl][j] = (uint8_t)intra_ref_sample(pl ? f.d_rec_v : f.d_rec_u, f.stride_c, x0 / 2, y0 / 2, NC, j, bL, bT, bTR);
+    }
+    __syncthreads();
+    if (tid <= 4 * N) {
+        const int a = s_ref[0][tid];
+        s_ref[1][tid] = (tid == 0 || tid == 4 * N) ? (uint8_t)a : (uint8_t)((s_ref[0][tid - 1] + 2 * a + s_ref[0][tid + 1] + 2) >> 2);
+    }
+    if (wave == 0) intra_dc_value<N>(s_ref[0], lane, &s_dc);
+    if (wave == 1) intra_dc_value<NC>(s_refc[0], lane, &s_dcc[0]);
+    if (wave == 2) intra_dc_value<NC>(s_refc[1], lane, &s_dcc[1]);
+    if (tid == 255) {
+        // most probable modes (:1268-1293).  The mode above counts only inside the same CU there (`bT && uiY`
+        // with uiY the offset inside the CU, always 0): it is DC whatever the CU above chose.
+        const int left = bL ? f.d_mode_y[cu - 1] : 1, top = 1;
+        int m0, m1, m2;
+        if (left == top) {
+            if (left > 1)
+                m0 = left, m1 = ((left + 29) % 32) + 2, m2 = ((left - 1) % 32) + 2;
+            else
+                m0 = 0, m1 = 1, m2 = 26;
+        } else {
+            m0 = left, m1 = top;
+            m2 = (left != 0 && top != 0) ? 0 : (left + top) < 2 ? 26 : 1;
+        }
+        s_mpm[0] = m0, s_mpm[1] = m1, s_mpm[2] = m2;
+    }
+    int sp[PER];
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+        const int i = lane + 64 * t;
+        sp[t] = f.d_src_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))];
+    }
+    int su[PERC], sv[PERC];
+#pragma unroll
+    for (int t = 0; t < PERC; t++) {
+        const int i = lane + 64 * t;
+        const int64_t o = (int64_t)(y0 / 2 + (i >> L2C)) * f.stride_c + x0 / 2 + (i & (NC - 1));
+        su[t] = f.d_src_u[o];
+        sv[t] = f.d_src_v[o];
+    }
+    __syncthreads();
+
+    // ---- luma decision ----
+    const int dc = s_dc;
+    intra_luma_sads<N, PER>(s_ref, sp, dc, wave, lane, s_sad);
+    __syncthreads();
+    if (tid == 0) {
+        const x265amd_intra_best b = intra_luma_argmin(s_sad, s_mpm[0], s_mpm[1], s_mpm[2], w.lambda);
+        s_best = (int)b.mode;
+        f.d_mode_y[cu] = (uint8_t)b.mode;
+        if (f.d_cost_y) f.d_cost_y[cu] = b.cost;
+    }
+    __syncthreads();
+    const int bm = s_best;
+    {
+        const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][bm]];
+        for (int i = tid; i < NPIX; i += 256)
+            f.d_pred_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))] = (uint8_t)intra_pixel<N>(ref, bm, i >> L2, i & (N - 1), dc);
+    }
+
+    // ---- chroma decision (:781-853): candidates in the reference's order, the one equal to the luma mode replaced
+    //      by 34, LM (index 4) skipped; cost = SAD(U) + SAD(V); first strict minimum ----
+    auto cand_mode = [&](int k) -> int {
+        const int base[4] = {0, 26, 10, 1};
+        if (k == 5) return bm;
+        int firstdup = 4;
+        for (int j = 3; j >= 0; j--)
+            if (base[j] == bm) firstdup = j;
+        return k == firstdup ? 34 : base[k];
+    };
+    for (int k = wave; k < 6; k += 4) {
+        if (k == 4) continue;  // wave-uniform
+        const int mode = cand_mode(k);
+        uint32_t s = 0;
+#pragma unroll
+        for (int t = 0; t < PERC; t++) {
+            const int i = lane + 64 * t;
+            s += (uint32_t)abs(su[t] - intra_pixel<NC, false>(s_refc[0], mode, i >> L2C, i & (NC - 1), s_dcc[0]));
+            s += (uint32_t)abs(sv[t] - intra_pixel<NC, false>(s_refc[1], mode, i >> L2C, i & (NC - 1), s_dcc[1]));
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) s_sadc[k] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t bc = X265AMD_MAX_SAD;
+        int bk = 0;
+        for (int k = 0; k < 6; k++) {
+            if (k == 4) continue;
+            if (s_sadc[k] < bc) {
+                bc = s_sadc[k];
+                bk = k;
+            }
+        }
+        const int real = cand_mode(bk);
+        s_bestc = real;
+        f.d_mode_c[cu] = (uint8_t)real;
+        if (f.d_cost_c) f.d_cost_c[cu] = bc;
+    }
+    __syncthreads();
+    const int bmc = s_bestc;
+    for (int i = tid; i < 2 * NPIXC; i += 256) {
+        const int pl = i >= NPIXC, j = i - pl * NPIXC;
+        const int64_t o = (int64_t)(y0 / 2 + (j >> L2C)) * f.stride_c + x0 / 2 + (j & (NC - 1));
+        (pl ? f.d_pred_v : f.d_pred_u)[o] = (uint8_t)intra_pixel<NC, false>(s_refc[pl], bmc, j >> L2C, j & (NC - 1), s_dcc[pl]);
     }
 }
 
@@ -180,4 +372,84 @@ extern "C" int x265amd_intra_decide_luma(const uint8_t *d_src, int src_stride, i
     }
 #undef X265AMD_INTRA_LAUNCH
     return hip_status(hipGetLastError());
+}
+
+static int intra_frame_check(const x265amd_intra_frame *f)
+{
+    if (!f) return X265AMD_ERR_ARG;
+    if (!f->d_src_y || !f->d_src_u || !f->d_src_v || !f->d_rec_y || !f->d_rec_u || !f->d_rec_v || !f->d_pred_y ||
+        !f->d_pred_u || !f->d_pred_v || !f->d_mode_y || !f->d_mode_c || !f->d_level_y || !f->d_level_u || !f->d_level_v)
+        return X265AMD_ERR_ARG;
+    if (f->cu != 16 && f->cu != 32) return X265AMD_ERR_ARG;  // src/params.cpp:76, inc/config.h:38
+    if (f->width <= 0 || f->height <= 0 || f->width % f->cu || f->height % f->cu) return X265AMD_ERR_ARG;
+    if (f->stride_y < f->width || f->stride_c < f->width / 2 || f->qp < 0 || f->qp > 51) return X265AMD_ERR_ARG;
+    return X265AMD_OK;
+}
+
+static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st)
+{
+    IntraWave w;
+    w.f = *f;
+    w.ncx = f->width / f->cu;
+    w.ncy = f->height / f->cu;
+    w.d = d;
+    w.lambda = (uint32_t)f->qp;  // src/encode.cpp:597
+    // cux = d - 2 cuy in [0, ncx): cuy from ceil((d - ncx + 1) / 2) to d / 2
+    const int lo = d - (w.ncx - 1) > 0 ? (d - (w.ncx - 1) + 1) / 2 : 0;
+    const int hi = d / 2 < w.ncy - 1 ? d / 2 : w.ncy - 1;
+    if (hi < lo) return X265AMD_OK;
+    w.cy_lo = lo;
+    const dim3 grid((unsigned)(hi - lo + 1)), block(256);
+    if (f->cu == 16)
+        hipLaunchKernelGGL(intra_wave_kernel<16>, grid, block, 0, st, w);
+    else
+        hipLaunchKernelGGL(intra_wave_kernel<32>, grid, block, 0, st, w);
+    return hip_status(hipGetLastError());
+}
+
+extern "C" int x265amd_intra_waves(const x265amd_intra_frame *f)
+{
+    if (intra_frame_check(f) != X265AMD_OK) return -1;
+    return f->width / f->cu + 2 * (f->height / f->cu - 1);
+}
+
+extern "C" int x265amd_intra_predict_wave(const x265amd_intra_frame *f, int wave, void *stream)
+{
+    if (!initialised()) return X265AMD_ERR_NOT_INIT;
+    const int rc = intra_frame_check(f);
+    if (rc != X265AMD_OK) return rc;
+    if (wave < 0 || wave >= x265amd_intra_waves(f)) return X265AMD_ERR_ARG;
+    return intra_wave_launch(f, wave, (hipStream_t)stream);
+}
+
+extern "C" int x265amd_intra_encode_frame(const x265amd_intra_frame *f, void *stream)
+{
+    if (!initialised()) return X265AMD_ERR_NOT_INIT;
+    int rc = intra_frame_check(f);
+    if (rc != X265AMD_OK) return rc;
+    // the transform stage of a wave: forward + inverse of the three planes (Stage 3a / 3b, src/encode.cpp:863-925),
+    // every TU of the plane each time -- TUs of earlier waves come out as they already are (same source, same
+    // prediction), TUs of later waves are overwritten when their wave comes
+    x265amd_tq_desc ty = {}, tu = {}, tv = {};
+    ty.width = f->width, ty.height = f->height, ty.tu = f->cu, ty.qp = f->qp, ty.slice_type = X265AMD_SLICE_I, ty.nframes = 1;
+    ty.d_src = f->d_src_y, ty.src_stride = f->stride_y;
+    ty.d_pred = f->d_pred_y, ty.pred_stride = f->stride_y;
+    ty.d_level = f->d_level_y, ty.level_stride = f->stride_y;
+    ty.d_rec = f->d_rec_y, ty.rec_stride = f->stride_y;
+    ty.d_abs_sum = f->d_abs_sum_y;
+    tu.width = f->width / 2, tu.height = f->height / 2, tu.tu = f->cu / 2, tu.qp = x265amd_chroma_qp(f->qp);
+    tu.slice_type = X265AMD_SLICE_I, tu.nframes = 1;
+    tu.src_stride = tu.pred_stride = tu.level_stride = tu.rec_stride = f->stride_c;
+    tv = tu;
+    tu.d_src = f->d_src_u, tu.d_pred = f->d_pred_u, tu.d_level = f->d_level_u, tu.d_rec = f->d_rec_u, tu.d_abs_sum = f->d_abs_sum_u;
+    tv.d_src = f->d_src_v, tv.d_pred = f->d_pred_v, tv.d_level = f->d_level_v, tv.d_rec = f->d_rec_v, tv.d_abs_sum = f->d_abs_sum_v;
+    const int nw = x265amd_intra_waves(f);
+    for (int d = 0; d < nw; d++) {
+        rc = intra_wave_launch(f, d, (hipStream_t)stream);
+        if (rc == X265AMD_OK) rc = x265amd_tq_roundtrip(&ty, stream);
+        if (rc == X265AMD_OK) rc = x265amd_tq_roundtrip(&tu, stream);
+        if (rc == X265AMD_OK) rc = x265amd_tq_roundtrip(&tv, stream);
+        if (rc != X265AMD_OK) return rc;
+    }
+    return X265AMD_OK;
 }
