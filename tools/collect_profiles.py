@@ -5,7 +5,7 @@ per round:  python tools/collect_profiles.py r2
   rocprofv3 kernel stats-> profiles/<round>_<workload>_kernel_stats.csv
   PMC traffic           -> profiles/pmc_traffic.json (the file bench.py reads) and profiles/<round>_pmc_traffic.json
   SQ counter summaries  -> profiles/<round>_pmc_sq.json
-  PU search timings     -> profiles/<round>_pu_bench.txt"""
+  PU search / intra frame timings, TQ wave trace -> profiles/<round>_{pu_bench,intra_bench,tq_trace}.txt"""
 import glob
 import json
 import os
@@ -49,10 +49,12 @@ def main():
         with open(os.path.join(DST, f"{rnd}_pmc_sq.json"), "w") as o:
             json.dump(sq, o, indent=1, sort_keys=True)
         n += 1
-    p = os.path.join(SRC, "pu_bench.txt")
-    if os.path.exists(p):
-        shutil.copy(p, os.path.join(DST, f"{rnd}_pu_bench.txt"))
-        n += 1
+    for name in ("pu_bench", "intra_bench", "tq_trace"):
+        p = os.path.join(SRC, name + ".txt")
+        if os.path.exists(p):
+            with open(p) as i, open(os.path.join(DST, f"{rnd}_{name}.txt"), "w") as o:
+                o.writelines(line for line in i if "amdgpu.ids" not in line)
+            n += 1
     print(n, "files into", DST)
 
 

@@ -19,6 +19,8 @@ bench)
   done
   echo "tq done"
   timeout -k 10 200 python tools/pu_bench.py > $OUT/pu_bench.txt 2>&1; echo "pu done"
+  timeout -k 10 300 python tools/intra_bench.py > $OUT/intra_bench.txt 2>&1; echo "intra done"
+  timeout -k 10 100 python tools/tq_trace.py 32 16 > $OUT/tq_trace.txt 2>&1; echo "tq trace done"
   ;;
 trace)
   cd /tmp && export TMPDIR=/tmp

@@ -376,12 +376,28 @@ class IntraFrame(C.Structure):
                                            "d_abs_sum_y", "d_abs_sum_u", "d_abs_sum_v")])
 
 
-def intra_encode_frame(y, u, v, cu, qp, wave_by_wave=False):
+def intra_frame_buffers(h, w, cu, device):
+    """The output planes of intra_encode_frame.  U and V are the two halves of one tensor each (as in a 4:2:0 frame
+    buffer), which lets the library run their transform stage as one batched launch."""
+    ncus = (h // cu) * (w // cu) if cu in (16, 32) else 0
+    z8 = lambda *s: torch.zeros(s, dtype=torch.uint8, device=device)
+    rec_c, pred_c = z8(2, h // 2, w // 2), z8(2, h // 2, w // 2)
+    level_c = torch.zeros((2, h // 2, w // 2), dtype=torch.int16, device=device)
+    sum_c = torch.zeros((2, ncus), dtype=torch.int32, device=device)
+    zi = lambda: torch.zeros(ncus, dtype=torch.int32, device=device)
+    return {"rec_y": z8(h, w), "rec_u": rec_c[0], "rec_v": rec_c[1], "pred_y": z8(h, w), "pred_u": pred_c[0], "pred_v": pred_c[1],
+            "level_y": torch.zeros((h, w), dtype=torch.int16, device=device), "level_u": level_c[0], "level_v": level_c[1],
+            "mode_y": z8(ncus), "mode_c": z8(ncus), "cost_y": zi(), "cost_c": zi(),
+            "abs_sum_y": zi(), "abs_sum_u": sum_c[0], "abs_sum_v": sum_c[1]}
+
+
+def intra_encode_frame(y, u, v, cu, qp, wave_by_wave=False, out=None):
     """One intra frame on the GPU (x265amd_intra_encode_frame): the pixel path of the reference's encode loop.
     y: uint8 [H][W]; u, v: uint8 [H/2][W/2] (contiguous).  Returns a dict: rec_y / rec_u / rec_v, mode_y / mode_c
     (uint8 [ncus]), cost_y / cost_c (int32 [ncus]), level_y / level_u / level_v (int16 planes), abs_sum_y / _u / _v.
     wave_by_wave: drive the anti-diagonals from here (x265amd_intra_predict_wave + x265amd_tq_roundtrip per plane)
-    instead of the library's own loop -- the same launches."""
+    instead of the library's own loop -- the same launches.  out: buffers of an earlier call / intra_frame_buffers
+    to reuse (no allocation in the call: it can then be captured into a graph)."""
     for t, n in ((y, "y"), (u, "u"), (v, "v")):
         _dev(t, torch.uint8, n)
         if t.dim() != 2 or not t.is_contiguous():
@@ -391,15 +407,7 @@ def intra_encode_frame(y, u, v, cu, qp, wave_by_wave=False):
         raise ValueError("u, v: need [H/2][W/2]")
     ncus = (h // cu) * (w // cu) if cu in (16, 32) else 0
     dv = y.device
-    o = {"rec_y": torch.zeros_like(y), "rec_u": torch.zeros_like(u), "rec_v": torch.zeros_like(v),
-         "pred_y": torch.zeros_like(y), "pred_u": torch.zeros_like(u), "pred_v": torch.zeros_like(v),
-         "level_y": torch.zeros((h, w), dtype=torch.int16, device=dv),
-         "level_u": torch.zeros((h // 2, w // 2), dtype=torch.int16, device=dv),
-         "level_v": torch.zeros((h // 2, w // 2), dtype=torch.int16, device=dv),
-         "mode_y": torch.zeros(ncus, dtype=torch.uint8, device=dv), "mode_c": torch.zeros(ncus, dtype=torch.uint8, device=dv),
-         "cost_y": torch.zeros(ncus, dtype=torch.int32, device=dv), "cost_c": torch.zeros(ncus, dtype=torch.int32, device=dv),
-         "abs_sum_y": torch.zeros(ncus, dtype=torch.int32, device=dv), "abs_sum_u": torch.zeros(ncus, dtype=torch.int32, device=dv),
-         "abs_sum_v": torch.zeros(ncus, dtype=torch.int32, device=dv)}
+    o = out if out is not None else intra_frame_buffers(h, w, cu, dv)
     f = IntraFrame()
     f.width, f.height, f.cu, f.qp, f.stride_y, f.stride_c = w, h, cu, qp, w, w // 2
     f.d_src_y, f.d_src_u, f.d_src_v = y.data_ptr(), u.data_ptr(), v.data_ptr()

@@ -28,6 +28,7 @@ __device__ const int16_t kIntraInvAngle[35] = {0,   0,   256, 315, 390, 482, 630
                                                256, 315, 390, 482, 630, 910, 1638, 4096, 0,  4096, 1638, 910, 630, 482, 390, 315, 256};
 
 constexpr int kMaxRef = 4 * 32 + 1;
+constexpr int kMainRow = 3 * 32 + 8;  // refMain of a mode: samples -N .. 2N, and one past the end that a zero weight may touch
 
 // pixel (r, c) of mode `mode`; ref = the sample array the mode reads (smoothed or not), dc = the DC value.
 // LUMA: the edge smoothing of DC and of the pure horizontal / vertical modes (bLuma of the reference's functions)
@@ -69,7 +70,49 @@ template <int N, bool LUMA = true> __device__ __forceinline__ int intra_pixel(co
     return p;
 }
 
-// ---- pieces shared by the two kernels (one workgroup of 256 threads per CU) ----
+// The main reference row of an angular mode, the reference's refMain (src/encode.cpp:1461-1485), in LDS: entry
+// i + N holds sample i, i in ((N * angle) >> 5, 2 N]: the main side, and for negative i the other side projected
+// onto it.  One wave fills its own row (two or three entries a lane) and reads it back: same-wave LDS accesses
+// complete in order, the fence keeps the compiler from moving the reads up.
+template <int N> __device__ __forceinline__ void intra_fill_main(const uint8_t *ref, int mode, int lane, uint8_t *row)
+{
+    const uint8_t *tl = ref + 2 * N;
+    const bool hor = mode < 18;
+    const int ang = kIntraAngle[mode], inv = kIntraInvAngle[mode];
+    const int sgn = hor ? -1 : 1;
+    const int lo = ang < 0 ? ((N * ang) >> 5) + 1 : 0;
+    for (int i = lane - N; i <= 2 * N; i += 64) {
+        int v = 0;
+        if (i >= 0)
+            v = tl[sgn * i];
+        else if (i >= lo)
+            v = tl[-sgn * ((128 + (-i) * inv) >> 8)];
+        row[i + N] = (uint8_t)v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// pixel (r, c) of angular mode `mode` from its main row (see intra_pixel for the construction)
+template <int N, bool LUMA> __device__ __forceinline__ int intra_ang_pixel(const uint8_t *ref, const uint8_t *row, int mode, int r, int c)
+{
+    const bool hor = mode < 18;
+    const int ang = kIntraAngle[mode];
+    const int k = hor ? c : r, x = hor ? r : c;
+    const int pos = (k + 1) * ang;
+    const int idx = pos >> 5, fact = pos & 31;
+    const uint8_t *m = row + N + x + idx + 1;
+    int p = m[0];
+    if (fact) p = ((32 - fact) * p + fact * m[1] + 16) >> 5;
+    if (LUMA && ang == 0 && x == 0) {
+        const uint8_t *tl = ref + 2 * N;
+        p += (tl[(hor ? 1 : -1) * (k + 1)] - tl[0]) >> 1;
+        p = min(max(p, 0), 255);
+    }
+    return p;
+}
+
+// ---- pieces shared by the two kernels (one workgroup per CU) ----
 
 // the DC value of a sample array (src/encode.cpp:1398-1416), by wave 0; the caller puts a barrier after it
 template <int N> __device__ __forceinline__ void intra_dc_value(const uint8_t *ref, int lane, int *out)
@@ -80,20 +123,29 @@ template <int N> __device__ __forceinline__ void intra_dc_value(const uint8_t *r
     if (lane == 0) *out = (s + N) / (2 * N);
 }
 
-// SADs of the 35 luma modes (dealt round the four waves) into s_sad[]; s_ref = samples and smoothed samples, sp[] =
+// SADs of the 35 luma modes (dealt round the workgroup's waves) into s_sad[]; s_ref = samples and smoothed samples, sp[] =
 // the lane's source pixels i = lane + 64 t.  The caller puts a barrier after it.
-template <int N, int PER>
+template <int N, int PER, int NWAVES = 4>
 __device__ __forceinline__ void intra_luma_sads(const uint8_t (*s_ref)[kMaxRef + 3], const int (&sp)[PER], int dc, int wave, int lane,
-                                                uint32_t *s_sad)
+                                                uint32_t *s_sad, uint8_t *main_row)
 {
     constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
-    for (int mode = wave; mode < 35; mode += 4) {
+    for (int mode = wave; mode < 35; mode += NWAVES) {
         const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][mode]];
         uint32_t s = 0;
+        if (mode >= 2) {  // wave-uniform
+            intra_fill_main<N>(ref, mode, lane, main_row);
 #pragma unroll
-        for (int t = 0; t < PER; t++) {
-            const int i = lane + 64 * t;
-            if (i < N * N) s += (uint32_t)abs(sp[t] - intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc));
+            for (int t = 0; t < PER; t++) {
+                const int i = lane + 64 * t;
+                if (i < N * N) s += (uint32_t)abs(sp[t] - intra_ang_pixel<N, true>(ref, main_row, mode, i >> L2, i & (N - 1)));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < PER; t++) {
+                const int i = lane + 64 * t;
+                if (i < N * N) s += (uint32_t)abs(sp[t] - intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc));
+            }
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) s_sad[mode] = s;
@@ -125,6 +177,7 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(const uint8_t *__rest
     constexpr int NPIX = N * N;
     constexpr int PER = (NPIX + 63) / 64;  // pixels of a mode per lane
     __shared__ uint8_t s_ref[2][kMaxRef + 3];
+    __shared__ uint8_t s_main[4][kMainRow];
     __shared__ uint32_t s_sad[35];
     __shared__ int s_dc, s_best;
     const int cu = blockIdx.x;
@@ -153,7 +206,7 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(const uint8_t *__rest
     }
     __syncthreads();
     const int dc = s_dc;
-    intra_luma_sads<N, PER>(s_ref, sp, dc, wave, lane, s_sad);
+    intra_luma_sads<N, PER>(s_ref, sp, dc, wave, lane, s_sad, s_main[wave]);
     __syncthreads();
     if (tid == 0) {
         const uint8_t *mpm = mpms + 3 * (int64_t)cu;
@@ -213,9 +266,13 @@ __device__ __forceinline__ int intra_ref_sample(const uint8_t *rec, int stride, 
     return raw(off[m + 1] - 1);
 }
 
+// 16 waves per CU here: an anti-diagonal has few CUs (34 at 1080p with CU 32), so the launch is as long as one
+// CU takes, and the 35 + 5 candidate modes of a CU are what there is to spread
+constexpr int kWaveThreads = 1024;
 template <int N>
-__global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
+__global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWave w)
 {
+    constexpr int NT = kWaveThreads, NWAVES = NT / 64;
     constexpr int L2 = N == 16 ? 4 : 5;
     constexpr int NC = N / 2, L2C = L2 - 1;
     constexpr int NPIX = N * N, PER = NPIX / 64;
@@ -223,6 +280,7 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
     const x265amd_intra_frame &f = w.f;
     __shared__ uint8_t s_ref[2][kMaxRef + 3];
     __shared__ uint8_t s_refc[2][4 * 16 + 4];  // U, V: chroma reads the samples as they are
+    __shared__ uint8_t s_main[NWAVES][2][kMainRow];
     __shared__ uint32_t s_sad[35], s_sadc[6];
     __shared__ int s_dc, s_dcc[2], s_best, s_bestc, s_mpm[3];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -234,7 +292,7 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
 
     // ---- reference samples: luma, and its smoothed copy; U and V ----
     if (tid <= 4 * N) s_ref[0][tid] = (uint8_t)intra_ref_sample(f.d_rec_y, f.stride_y, x0, y0, N, tid, bL, bT, bTR);
-    for (int i = tid; i < 2 * (4 * NC + 1); i += 256) {
+    for (int i = tid; i < 2 * (4 * NC + 1); i += NT) {
         const int pl = i >= 4 * NC + 1, j = i - pl * (4 * NC + 1);
         s_refc[pl][j] = (uint8_t)intra_ref_sample(pl ? f.d_rec_v : f.d_rec_u, f.stride_c, x0 / 2, y0 / 2, NC, j, bL, bT, bTR);
     }
@@ -246,7 +304,7 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
     if (wave == 0) intra_dc_value<N>(s_ref[0], lane, &s_dc);
     if (wave == 1) intra_dc_value<NC>(s_refc[0], lane, &s_dcc[0]);
     if (wave == 2) intra_dc_value<NC>(s_refc[1], lane, &s_dcc[1]);
-    if (tid == 255) {
+    if (tid == NT - 1) {
         // most probable modes (:1268-1293).  The mode above counts only inside the same CU there (`bT && uiY`
         // with uiY the offset inside the CU, always 0): it is DC whatever the CU above chose.
         const int left = bL ? f.d_mode_y[cu - 1] : 1, top = 1;
@@ -280,7 +338,7 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
 
     // ---- luma decision ----
     const int dc = s_dc;
-    intra_luma_sads<N, PER>(s_ref, sp, dc, wave, lane, s_sad);
+    intra_luma_sads<N, PER, NWAVES>(s_ref, sp, dc, wave, lane, s_sad, s_main[wave][0]);
     __syncthreads();
     if (tid == 0) {
         const x265amd_intra_best b = intra_luma_argmin(s_sad, s_mpm[0], s_mpm[1], s_mpm[2], w.lambda);
@@ -292,7 +350,7 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
     const int bm = s_best;
     {
         const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][bm]];
-        for (int i = tid; i < NPIX; i += 256)
+        for (int i = tid; i < NPIX; i += NT)
             f.d_pred_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))] = (uint8_t)intra_pixel<N>(ref, bm, i >> L2, i & (N - 1), dc);
     }
 
@@ -306,15 +364,26 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
             if (base[j] == bm) firstdup = j;
         return k == firstdup ? 34 : base[k];
     };
-    for (int k = wave; k < 6; k += 4) {
+    for (int k = wave; k < 6; k += NWAVES) {
         if (k == 4) continue;  // wave-uniform
         const int mode = cand_mode(k);
         uint32_t s = 0;
+        if (mode >= 2) {  // wave-uniform
+            intra_fill_main<NC>(s_refc[0], mode, lane, s_main[wave][0]);
+            intra_fill_main<NC>(s_refc[1], mode, lane, s_main[wave][1]);
 #pragma unroll
-        for (int t = 0; t < PERC; t++) {
-            const int i = lane + 64 * t;
-            s += (uint32_t)abs(su[t] - intra_pixel<NC, false>(s_refc[0], mode, i >> L2C, i & (NC - 1), s_dcc[0]));
-            s += (uint32_t)abs(sv[t] - intra_pixel<NC, false>(s_refc[1], mode, i >> L2C, i & (NC - 1), s_dcc[1]));
+            for (int t = 0; t < PERC; t++) {
+                const int i = lane + 64 * t;
+                s += (uint32_t)abs(su[t] - intra_ang_pixel<NC, false>(s_refc[0], s_main[wave][0], mode, i >> L2C, i & (NC - 1)));
+                s += (uint32_t)abs(sv[t] - intra_ang_pixel<NC, false>(s_refc[1], s_main[wave][1], mode, i >> L2C, i & (NC - 1)));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < PERC; t++) {
+                const int i = lane + 64 * t;
+                s += (uint32_t)abs(su[t] - intra_pixel<NC, false>(s_refc[0], mode, i >> L2C, i & (NC - 1), s_dcc[0]));
+                s += (uint32_t)abs(sv[t] - intra_pixel<NC, false>(s_refc[1], mode, i >> L2C, i & (NC - 1), s_dcc[1]));
+            }
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) s_sadc[k] = s;
@@ -337,7 +406,7 @@ __global__ __launch_bounds__(256) void intra_wave_kernel(const IntraWave w)
     }
     __syncthreads();
     const int bmc = s_bestc;
-    for (int i = tid; i < 2 * NPIXC; i += 256) {
+    for (int i = tid; i < 2 * NPIXC; i += NT) {
         const int pl = i >= NPIXC, j = i - pl * NPIXC;
         const int64_t o = (int64_t)(y0 / 2 + (j >> L2C)) * f.stride_c + x0 / 2 + (j & (NC - 1));
         (pl ? f.d_pred_v : f.d_pred_u)[o] = (uint8_t)intra_pixel<NC, false>(s_refc[pl], bmc, j >> L2C, j & (NC - 1), s_dcc[pl]);
@@ -399,7 +468,7 @@ static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st
     const int hi = d / 2 < w.ncy - 1 ? d / 2 : w.ncy - 1;
     if (hi < lo) return X265AMD_OK;
     w.cy_lo = lo;
-    const dim3 grid((unsigned)(hi - lo + 1)), block(256);
+    const dim3 grid((unsigned)(hi - lo + 1)), block(kWaveThreads);
     if (f->cu == 16)
         hipLaunchKernelGGL(intra_wave_kernel<16>, grid, block, 0, st, w);
     else
@@ -443,12 +512,24 @@ extern "C" int x265amd_intra_encode_frame(const x265amd_intra_frame *f, void *st
     tv = tu;
     tu.d_src = f->d_src_u, tu.d_pred = f->d_pred_u, tu.d_level = f->d_level_u, tu.d_rec = f->d_rec_u, tu.d_abs_sum = f->d_abs_sum_u;
     tv.d_src = f->d_src_v, tv.d_pred = f->d_pred_v, tv.d_level = f->d_level_v, tv.d_rec = f->d_rec_v, tv.d_abs_sum = f->d_abs_sum_v;
+    // U and V in one launch (a batch of two planes) when the four V planes sit at one common distance behind
+    // their U planes, as they do in a 4:2:0 frame buffer
+    const int64_t du = f->d_src_v - f->d_src_u;
+    const bool both = du > 0 && f->d_pred_v - f->d_pred_u == du && f->d_rec_v - f->d_rec_u == du &&
+                      f->d_level_v - f->d_level_u == du && du >= (int64_t)tu.height * f->stride_c &&
+                      (!f->d_abs_sum_u == !f->d_abs_sum_v) &&
+                      (!f->d_abs_sum_u || f->d_abs_sum_v - f->d_abs_sum_u >= (int64_t)(tu.height / tu.tu) * (tu.width / tu.tu));
+    if (both) {
+        tu.nframes = 2;
+        tu.src_frame_stride = tu.pred_frame_stride = tu.rec_frame_stride = tu.level_frame_stride = du;
+        tu.abs_sum_frame_stride = f->d_abs_sum_u ? f->d_abs_sum_v - f->d_abs_sum_u : 0;
+    }
     const int nw = x265amd_intra_waves(f);
     for (int d = 0; d < nw; d++) {
         rc = intra_wave_launch(f, d, (hipStream_t)stream);
         if (rc == X265AMD_OK) rc = x265amd_tq_roundtrip(&ty, stream);
         if (rc == X265AMD_OK) rc = x265amd_tq_roundtrip(&tu, stream);
-        if (rc == X265AMD_OK) rc = x265amd_tq_roundtrip(&tv, stream);
+        if (rc == X265AMD_OK && !both) rc = x265amd_tq_roundtrip(&tv, stream);
         if (rc != X265AMD_OK) return rc;
     }
     return X265AMD_OK;
