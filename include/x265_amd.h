@@ -284,7 +284,9 @@ typedef struct x265amd_tq_desc {
      * prediction output / co-located block).  With d_mv != NULL: the REFERENCE
      * picture; the prediction of pixel (x, y) is ref[y + mvy][x + mvx] with the
      * vector of the mv_ctu x mv_ctu block containing (x, y) -- integer-pel motion
-     * compensation fused into the load (see mv_shift below). */
+     * compensation fused into the load (see mv_shift below).  The vectors must keep every compensated
+     * block inside the prediction plane, as the library's own searches guarantee ("legal" candidates,
+     * SURVEY App. A.7): the kernels do not clamp, a vector from elsewhere that points outside reads outside. */
     const uint8_t *d_pred;
     int32_t pred_stride;
     int64_t pred_frame_stride;

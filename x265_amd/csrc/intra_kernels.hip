@@ -13,6 +13,7 @@
 // four waves; thread 0 does the argmin in mode order.  On request the winner's prediction is written out for the
 // residual stage (src/encode.cpp:867).
 #include "common.h"
+#include "tq_common.h"
 
 namespace x265amd {
 
@@ -496,8 +497,9 @@ extern "C" int x265amd_intra_encode_frame(const x265amd_intra_frame *f, void *st
     if (!initialised()) return X265AMD_ERR_NOT_INIT;
     int rc = intra_frame_check(f);
     if (rc != X265AMD_OK) return rc;
-    // the transform stage of a wave: forward + inverse of the three planes (Stage 3a / 3b, src/encode.cpp:863-925),
-    // every TU of the plane each time -- TUs of earlier waves come out as they already are (same source, same
+    // the transform stage of a wave: forward + inverse of the three planes (Stage 3a / 3b, src/encode.cpp:863-925)
+    // over the 128 x 32 pixel tile units that hold the wave's CUs (the whole plane where the matrix-core kernel does
+    // not apply) -- TUs of earlier waves that share a unit come out as they already are (same source, same
     // prediction), TUs of later waves are overwritten when their wave comes
     x265amd_tq_desc ty = {}, tu = {}, tv = {};
     ty.width = f->width, ty.height = f->height, ty.tu = f->cu, ty.qp = f->qp, ty.slice_type = X265AMD_SLICE_I, ty.nframes = 1;
@@ -525,11 +527,17 @@ extern "C" int x265amd_intra_encode_frame(const x265amd_intra_frame *f, void *st
         tu.abs_sum_frame_stride = f->d_abs_sum_u ? f->d_abs_sum_v - f->d_abs_sum_u : 0;
     }
     const int nw = x265amd_intra_waves(f);
+    const int ncx = f->width / f->cu, ncy = f->height / f->cu;
+    const int l2 = f->cu == 16 ? 4 : 5;
     for (int d = 0; d < nw; d++) {
         rc = intra_wave_launch(f, d, (hipStream_t)stream);
-        if (rc == X265AMD_OK) rc = x265amd_tq_roundtrip(&ty, stream);
-        if (rc == X265AMD_OK) rc = x265amd_tq_roundtrip(&tu, stream);
-        if (rc == X265AMD_OK && !both) rc = x265amd_tq_roundtrip(&tv, stream);
+        // the transform stage follows the diagonal: only the tile units that hold its CUs
+        const int lo = d - (ncx - 1) > 0 ? (d - (ncx - 1) + 1) / 2 : 0;
+        const int hi = d / 2 < ncy - 1 ? d / 2 : ncy - 1;
+        const TqDiag dy{hi - lo + 1, d, lo, l2}, dc{hi - lo + 1, d, lo, l2 - 1};
+        if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&ty, dy, (hipStream_t)stream);
+        if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&tu, dc, (hipStream_t)stream);
+        if (rc == X265AMD_OK && !both) rc = tq_roundtrip_diag(&tv, dc, (hipStream_t)stream);
         if (rc != X265AMD_OK) return rc;
     }
     return X265AMD_OK;

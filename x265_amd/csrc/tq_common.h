@@ -16,11 +16,22 @@ struct TqParams {
     int mv_ctu_log2, mv_ctus_x;    // with d.d_mv: log2 of d.mv_ctu, vectors per picture row
     unsigned long long *d_trace;   // x265amd_debug_tq_trace: four 64-bit words per wave of tq_mfma_kernel, or null
     int trace_waves;               // .. and how many waves it has room for
+    // x265amd_intra_encode_frame: only the tile units that hold the CUs of one anti-diagonal (cux + 2 cuy == diag_d,
+    // cuy = diag_lo + blockIdx.x, CUs of 1 << diag_cu_log2 pixels in THIS plane); diag_count = 0: the whole plane
+    int diag_count, diag_d, diag_lo, diag_cu_log2;
 };
 
 enum { TQ_FWD = 1, TQ_INV = 2, TQ_BOTH = 3 };
 
 // tq_mfma.hip: all TU sizes, widths that are multiples of 16; the 4x4 DST (per-TU intra modes) stays with the butterfly kernel
 int launch_tq_mfma(int mode, const TqParams &p, hipStream_t stream);
+
+// what x265amd_intra_encode_frame tells the transform stage about the anti-diagonal it follows
+struct TqDiag {
+    int count, d, lo, cu_log2;
+};
+// x265amd_tq_roundtrip restricted to the tile units of an anti-diagonal's CUs where the matrix-core kernel runs
+// (the whole plane otherwise: the result is the same, see intra_kernels.hip)
+int tq_roundtrip_diag(const x265amd_tq_desc *desc, const TqDiag &diag, hipStream_t stream);
 
 }  // namespace x265amd

@@ -396,7 +396,7 @@ static int g_tq_path = 0;
 static unsigned long long *g_tq_trace = nullptr;
 static int g_tq_trace_waves = 0;
 
-template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_t stream, bool coef_in = false)
+template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_t stream, bool coef_in = false, const TqDiag *diag = nullptr)
 {
     if (!initialised()) return X265AMD_ERR_NOT_INIT;
     if (!desc) return X265AMD_ERR_ARG;
@@ -438,6 +438,14 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     p.mv_ctus_x = d.d_mv ? d.width / d.mv_ctu : 0;
     p.d_trace = g_tq_trace;
     p.trace_waves = g_tq_trace_waves;
+    p.diag_count = 0;
+    p.diag_d = p.diag_lo = p.diag_cu_log2 = 0;
+    if (diag && diag->count > 0) {
+        p.diag_count = diag->count;
+        p.diag_d = diag->d;
+        p.diag_lo = diag->lo;
+        p.diag_cu_log2 = diag->cu_log2;
+    }
     if (coef_in) {  // the plane already holds xDeQuant's output: (c * 1 + 0) >> 0, and the clip is a no-op on Int16
         p.dq_scale = 1;
         p.dq_rnd = 0;
@@ -459,6 +467,11 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     default: hipLaunchKernelGGL((tq_kernel<32, MODE>), grid, block, 0, stream, p); break;
     }
     return hip_status(hipGetLastError());
+}
+
+int tq_roundtrip_diag(const x265amd_tq_desc *desc, const TqDiag &diag, hipStream_t stream)
+{
+    return launch_tq<TQ_BOTH>(desc, stream, false, &diag);
 }
 
 }  // namespace x265amd

@@ -173,7 +173,11 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     const int ntxg = (p.tiles_x + 3) >> 2;
     const int nunits = ntxg * p.tiles_y * d.nframes;
     const int per = (nunits + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int u_beg = blockIdx.x * per, u_end = min(u_beg + per, nunits);
+    // diagonal mode (p.diag_count > 0): ONE unit per workgroup, the one that holds CU (diag_d - 2 cuy, cuy) of frame
+    // blockIdx.y, cuy = diag_lo + blockIdx.x (the launcher sizes the grid; units that two CUs share are done twice,
+    // to the same values)
+    const bool diag = p.diag_count > 0;
+    const int u_beg = diag ? 0 : blockIdx.x * per, u_end = diag ? 1 : min(u_beg + per, nunits);
     if (u_beg >= u_end) return;  // block-uniform; no barriers in this kernel
 
     // constant operands of this lane
@@ -305,6 +309,12 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
         const int rem = u_beg - pos0.f * upf;
         pos0.ty = rem / ntxg;
         pos0.txg = rem - pos0.ty * ntxg;
+        if (diag) {
+            const int cuy = p.diag_lo + (int)blockIdx.x, cux = p.diag_d - 2 * cuy;
+            pos0.f = (int)blockIdx.y;
+            pos0.ty = (cuy << p.diag_cu_log2) >> 5;
+            pos0.txg = ((cux << p.diag_cu_log2) >> 5) >> 2;
+        }
         pos0.f = __builtin_amdgcn_readfirstlane(pos0.f);
         pos0.ty = __builtin_amdgcn_readfirstlane(pos0.ty);
         pos0.txg = __builtin_amdgcn_readfirstlane(pos0.txg);
@@ -549,8 +559,18 @@ int launch_tq_mfma(int mode, const TqParams &p_in, hipStream_t stream)
     const int64_t resident = (int64_t)cu_count() * kWgPerCu;
     int64_t nwg = units < resident ? units : resident;
     if (g_units_per_wg > 0) nwg = (units + g_units_per_wg - 1) / g_units_per_wg;
+    dim3 grid((unsigned)nwg);
+    if (p.diag_count > 0) {
+        // every CU of the diagonal must lie inside the plane: the kernel takes its unit from the CU's position
+        const int cu = 1 << p.diag_cu_log2;
+        const int hi = p.diag_lo + p.diag_count - 1;
+        if (p.diag_cu_log2 < 3 || p.diag_cu_log2 > 5 || p.diag_lo < 0 || (hi + 1) * cu > p.d.height || p.diag_d - 2 * hi < 0 ||
+            (p.diag_d - 2 * p.diag_lo + 1) * cu > p.d.width || p.d.nframes > 65535)
+            return X265AMD_ERR_ARG;
+        nwg = (int64_t)p.diag_count * p.d.nframes;
+        grid = dim3((unsigned)p.diag_count, (unsigned)p.d.nframes);
+    }
     if (p.trace_waves < nwg * 4) p.d_trace = nullptr;
-    const dim3 grid((unsigned)nwg);
     if (mode == TQ_FWD)
         launch_mv<TQ_FWD>(grid, stream, p);
     else if (mode == TQ_INV)
