@@ -195,4 +195,68 @@ class GopEncoder {
     std::unique_ptr<DeviceBuffer> cur_, level_, mv_, cbf_, ws_;
 };
 
+// Intra pictures: the pixel path of xEncEncode's CU loop (src/encode.cpp:668-941) on the GPU, frame by frame --
+// neighbour samples, luma and chroma mode decisions, prediction, transform stage, reconstruction.  What comes back
+// is what Stage 4 (xWriteCU, the entropy coder: host code, not part of this path) consumes: per CU the luma mode,
+// the chroma mode, the coded-block sums, and the quantised levels; plus the reconstruction, over which the
+// reference takes its MD5 SEI (src/encode.cpp:945-950).
+class IntraEncoder {
+  public:
+    IntraEncoder(int width, int height, int cu, int qp, int device = 0, void *stream = nullptr)
+        : w_(width), h_(height), cu_(cu), qp_(qp), stream_(stream)
+    {
+        if (width <= 0 || height <= 0 || (cu != 16 && cu != 32) || width % cu || height % cu)  // src/params.cpp:73-77
+            throw Error(X265AMD_ERR_ARG, "IntraEncoder: CU 16 or 32, width and height multiples of it");
+        check(x265amd_init(device), "x265amd_init");
+        ysz_ = (size_t)width * height;
+        csz_ = ysz_ / 4;
+        fsz_ = ysz_ + 2 * csz_;
+        ncu_ = (size_t)(width / cu) * (height / cu);
+        src_.reset(new DeviceBuffer(fsz_));
+        rec_.reset(new DeviceBuffer(fsz_));
+        pred_.reset(new DeviceBuffer(fsz_));
+        level_.reset(new DeviceBuffer(2 * fsz_));
+        mode_.reset(new DeviceBuffer(2 * ncu_));
+        sum_.reset(new DeviceBuffer(4 * 3 * ncu_));
+        f_ = x265amd_intra_frame{};
+        f_.width = width, f_.height = height, f_.cu = cu, f_.qp = qp, f_.stride_y = width, f_.stride_c = width / 2;
+        f_.d_src_y = src_->as(), f_.d_src_u = src_->as(ysz_), f_.d_src_v = src_->as(ysz_ + csz_);
+        f_.d_rec_y = rec_->as(), f_.d_rec_u = rec_->as(ysz_), f_.d_rec_v = rec_->as(ysz_ + csz_);
+        f_.d_pred_y = pred_->as(), f_.d_pred_u = pred_->as(ysz_), f_.d_pred_v = pred_->as(ysz_ + csz_);
+        f_.d_level_y = level_->as<int16_t>(), f_.d_level_u = level_->as<int16_t>(2 * ysz_), f_.d_level_v = level_->as<int16_t>(2 * (ysz_ + csz_));
+        f_.d_mode_y = mode_->as(), f_.d_mode_c = mode_->as(ncu_);
+        f_.d_abs_sum_y = sum_->as<uint32_t>(), f_.d_abs_sum_u = sum_->as<uint32_t>(4 * ncu_), f_.d_abs_sum_v = sum_->as<uint32_t>(8 * ncu_);
+    }
+
+    size_t frame_bytes() const { return fsz_; }
+    size_t cus() const { return ncu_; }
+    int waves() const { return x265amd_intra_waves(&f_); }
+
+    // One frame, Y,U,V each (the reference's input format).  Asynchronous; fetch() waits.
+    void encode(const uint8_t *yuv)
+    {
+        check(x265amd_memcpy_h2d(src_->as(), yuv, fsz_, stream_), "x265amd_memcpy_h2d");
+        check(x265amd_intra_encode_frame(&f_, stream_), "x265amd_intra_encode_frame");
+    }
+
+    // reconstruction [W*H*3/2], levels [W*H*3/2] (Y,U,V like the picture), luma / chroma mode per CU, xQuant's
+    // sums [3][ncu] (what sets bCbf, src/encode.cpp:888-890).  Null pointers are skipped.
+    void fetch(uint8_t *rec, int16_t *level, uint8_t *mode_y, uint8_t *mode_c, uint32_t *abs_sum = nullptr)
+    {
+        if (rec) check(x265amd_memcpy_d2h(rec, rec_->as(), fsz_, stream_), "x265amd_memcpy_d2h");
+        if (level) check(x265amd_memcpy_d2h(level, level_->as(), 2 * fsz_, stream_), "x265amd_memcpy_d2h");
+        if (mode_y) check(x265amd_memcpy_d2h(mode_y, mode_->as(), ncu_, stream_), "x265amd_memcpy_d2h");
+        if (mode_c) check(x265amd_memcpy_d2h(mode_c, mode_->as(ncu_), ncu_, stream_), "x265amd_memcpy_d2h");
+        if (abs_sum) check(x265amd_memcpy_d2h(abs_sum, sum_->as(), 12 * ncu_, stream_), "x265amd_memcpy_d2h");
+        check(x265amd_stream_sync(stream_), "x265amd_stream_sync");
+    }
+
+  private:
+    int w_, h_, cu_, qp_;
+    void *stream_ = nullptr;
+    size_t ysz_ = 0, csz_ = 0, fsz_ = 0, ncu_ = 0;
+    std::unique_ptr<DeviceBuffer> src_, rec_, pred_, level_, mode_, sum_;
+    x265amd_intra_frame f_;
+};
+
 }  // namespace x265amd_host

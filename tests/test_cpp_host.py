@@ -104,3 +104,37 @@ def test_two_host_threads_share_one_device(gpu):
     assert os.path.exists(exe), "build first: make -C host"
     r = subprocess.run([exe, "0", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "two_hosts ok" in r.stdout, r.stderr + r.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_host_intra_encoder_reconstruction_md5(gpu, oracle, tmp_path):
+    """host/encode_i.cpp (x265amd_host::IntraEncoder over x265amd_intra_encode_frame, plain g++, the C-ABI only) on
+    BASELINE configs[0]: the reconstruction file it writes has, frame by frame, the MD5s the reference encoder
+    printed (tests/golden/intra_cfg1.json); modes and levels equal the oracle's restatement of the loop."""
+    import hashlib
+    import json
+    from x265_amd import synth
+    exe = os.path.join(ROOT, "x265_amd", "lib", "x265amd_encode_i")
+    assert os.path.exists(exe), "build it with make -C host (or __graft_entry__.build())"
+    with open(os.path.join(ROOT, "tests", "golden", "intra_cfg1.json")) as f:
+        doc = json.load(f)
+    w, h, cu, qp, nf = doc["width"], doc["height"], doc["cu"], doc["qp"], doc["frames"]
+    yuv = synth.make_intra_probe(w, h, nf)
+    src = tmp_path / "in.yuv"
+    yuv.tofile(src)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([exe, str(src), str(w), str(h), str(nf), str(cu), str(qp), prefix], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    fsz = w * h * 3 // 2
+    rec = np.fromfile(prefix + ".rec", np.uint8).reshape(nf, fsz)
+    lvl = np.fromfile(prefix + ".lvl", np.int16).reshape(nf, fsz)
+    modes = np.fromfile(prefix + ".modes", np.uint8).reshape(nf, 2, -1)
+    for fr in range(nf):
+        assert hashlib.md5(rec[fr].tobytes()).hexdigest() == doc["recon_md5"][fr], fr
+    orec, my, mc, olv = oracle.intra_encode_frame(yuv[2], w, h, cu, qp, want_levels=True)
+    np.testing.assert_array_equal(modes[2, 0], my)
+    np.testing.assert_array_equal(modes[2, 1], mc)
+    np.testing.assert_array_equal(lvl[2], olv)
+    # geometry the reference rejects (src/params.cpp:73-77) comes back as an error, not a crash
+    r = subprocess.run([exe, str(src), "100", "64", "1", "16", "30", prefix], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3 and "IntraEncoder" in r.stderr
