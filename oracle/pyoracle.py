@@ -321,5 +321,20 @@ class Reference(_Lib):
         return out[:n]
 
 
+    def write_intra_frames(self, yuv, w, h, cu, qp, rec, levels, mode_y, mode_c):
+        """The reference's bitstream writer over a pixel path computed elsewhere: yuv, rec uint8[nf][w*h*3/2],
+        levels int16[nf][w*h*3/2], mode_y / mode_c uint8[nf][ncus].  Returns (bytes_per_frame, bitstream)."""
+        nf = yuv.shape[0]
+        nbytes = np.zeros(nf, np.int32)
+        bs = np.zeros(yuv.size + 65536, np.uint8)
+        n = self.lib.ref_write_intra_frames(_p(_chk(yuv, np.uint8), _u8p), w, h, cu, qp, nf, _p(_chk(rec, np.uint8), _u8p),
+                                            _p(_chk(levels, np.int16), _i16p), _p(_chk(mode_y, np.uint8), _u8p),
+                                            _p(_chk(mode_c, np.uint8), _u8p), _p(bs, _u8p), bs.size,
+                                            nbytes.ctypes.data_as(C.POINTER(C.c_int32)))
+        if n < 0:
+            raise ValueError("reference rejects this geometry" if n == -1 else "a chroma mode is not among its CU's candidates")
+        return nbytes, bs[:n].copy()
+
+
 def have_reference():
     return os.path.exists(os.path.join(_HERE, "_ref", "libx265ref.so"))

@@ -16,6 +16,8 @@
 
 #include <string.h>
 
+void xWriteCU(X265_t *h, UInt nDepth, UInt bLastCU); /* src/encode.cpp:474: defined there, not declared in the header */
+
 extern "C" {
 
 struct ref_mv {
@@ -351,6 +353,129 @@ int ref_intra_record(const uint8_t *yuv, int w, int h, int cu, int qp, int frame
     free(buf);
     xEncFree(&hnd);
     return g_rec_n < cap ? g_rec_n : cap;
+}
+
+/* The reference's own bitstream writer over a pixel path computed elsewhere (x265amd_intra_encode_frame on the GPU):
+ * xEncEncode's frame sequence (src/encode.cpp:587-973) with Stages 1b .. 3b -- prediction, decisions, transform
+ * stage -- replaced by the caller's per-frame results; headers, xEncIntraLoadRef (for the most probable modes the
+ * mode syntax needs), xWriteCU, the cache / line-buffer updates and the slice end are the reference's functions,
+ * called in the reference's order.  This is INTEGRATION.md's recipe for intra pictures, executed.
+ *   rec, levels: [nframes][w*h*3/2] (Y,U,V, picture geometry); mode_y, mode_c: [nframes][ncus] (mode_c = the real
+ *   chroma mode).  bs_out receives the stream, bytes_out its size per frame.  Returns the total size, -1 on a
+ *   geometry the reference rejects, -2 if a chroma mode is not one of the CU's candidates. */
+int ref_write_intra_frames(const uint8_t *yuv, int w, int hgt, int cu, int qp, int nframes, const uint8_t *rec,
+                           const int16_t *levels, const uint8_t *mode_y, const uint8_t *mode_c, uint8_t *bs_out,
+                           int bs_cap, int32_t *bytes_out)
+{
+    static X265_t hnd;
+    X265_t *h = &hnd;
+    xDefaultParams(h);
+    h->usWidth = (UInt16)w;
+    h->usHeight = (UInt16)hgt;
+    h->ucMaxCUWidth = (UInt8)cu;
+    h->iQP = qp;
+    h->eSliceType = SLICE_I;
+    if (w % cu || hgt % cu || cu < 16 || cu > MAX_CU_SIZE || w > MAX_WIDTH) return -1;
+    xCheckParams(h);
+    xEncInit(h);
+    const size_t ysz = (size_t)w * hgt, csz = ysz / 4, fsz = ysz + 2 * csz;
+    const int ncx = w / cu, ncy = hgt / cu, nc = cu / 2;
+    UInt8 *buf = (UInt8 *)malloc(fsz + 65536);
+    X265_BitStream *pBS = &h->bs;
+    X265_Cache *c = &h->cache;
+    int pos = 0, bad = 0;
+    for (int f = 0; f < nframes && !bad; f++) {
+        X265_Frame fr;
+        fr.pucY = (UInt8 *)yuv + f * fsz;
+        fr.pucU = fr.pucY + ysz;
+        fr.pucV = fr.pucU + csz;
+        h->pFrameCur = &fr;
+        h->pFrameRec = &h->refn[MAX_REF_NUM];
+        h->iPoc++;
+        xBitStreamInit(pBS, buf, (Int)(fsz + 65536));
+        xPutBits32(pBS, 0x01000000); /* SPS, src/encode.cpp:626-631 */
+        xPutBits(pBS, 0x47, 8);
+        xPutBits(pBS, 0x01, 8);
+        xWriteSPS(h);
+        xBitFlush(pBS);
+        xPutBits32(pBS, 0x01000000); /* PPS, :633-638 */
+        xPutBits(pBS, 0x48, 8);
+        xPutBits(pBS, 0x01, 8);
+        xWritePPS(h);
+        xBitFlush(pBS);
+        xPutBits32(pBS, (h->iPoc == 0 ? 0x45010000 : 0x41010000)); /* slice, :657-662 */
+        xPutBits(pBS, 0x01, 8);
+        xWriteSliceHeader(h);
+        xEncCahceInit(h);
+        xCabacInit(h);
+        xCabacReset(&h->cabac);
+        const uint8_t *ry = rec + f * fsz, *ru = ry + ysz, *rv = ru + csz;
+        const int16_t *ly = levels + f * fsz, *lu = ly + ysz, *lv = lu + csz;
+        for (int cy = 0; cy < ncy && !bad; cy++) {
+            h->uiCUY = (UInt32)(cy * cu);
+            xEncCahceInitLine(h, (UInt)(cy * cu));
+            for (int cx = 0; cx < ncx; cx++) {
+                const int x0 = cx * cu, y0 = cy * cu, idx = f * ncx * ncy + cy * ncx + cx;
+                h->uiCUX = (UInt32)x0;
+                xEncCacheLoadCU(h, (UInt)x0, (UInt)y0);
+                xEncIntraLoadRef(h, 0, 0, (UInt)cu); /* ucMostModeY, bValid */
+                const int my = mode_y[idx], mc = mode_c[idx];
+                int cand[6] = {PLANAR_IDX, VER_IDX, HOR_IDX, DC_IDX, LM_CHROMA_IDX, my}; /* :781-793 */
+                for (int i = 0; i < 4; i++)
+                    if (cand[i] == my) {
+                        cand[i] = 34;
+                        break;
+                    }
+                int kc = -1;
+                for (int k = 0; k < 6 && kc < 0; k++)
+                    if (k != 4 && cand[k] == mc) kc = k;
+                if (kc < 0) {
+                    bad = 1;
+                    break;
+                }
+                c->nBestModeY = (UInt8)my;
+                c->nBestModeC = (UInt8)kc;
+                UInt32 sum[3] = {0, 0, 0};
+                for (int i = 0; i < cu; i++)
+                    for (int j = 0; j < cu; j++) {
+                        const Int16 v = ly[(size_t)(y0 + i) * w + x0 + j];
+                        c->psCoefY[i * MAX_CU_SIZE + j] = v;
+                        sum[0] += (UInt32)abs(v);
+                        c->pucRecY[i * MAX_CU_SIZE + j] = ry[(size_t)(y0 + i) * w + x0 + j];
+                    }
+                for (int i = 0; i < nc; i++)
+                    for (int j = 0; j < nc; j++) {
+                        const size_t o = (size_t)(y0 / 2 + i) * (w / 2) + x0 / 2 + j;
+                        c->psCoefU[i * MAX_CU_SIZE / 2 + j] = lu[o];
+                        c->psCoefV[i * MAX_CU_SIZE / 2 + j] = lv[o];
+                        sum[1] += (UInt32)abs(lu[o]);
+                        sum[2] += (UInt32)abs(lv[o]);
+                        c->pucRecU[i * MAX_CU_SIZE / 2 + j] = ru[o];
+                        c->pucRecV[i * MAX_CU_SIZE / 2 + j] = rv[o];
+                    }
+                c->bCbf[0] = sum[0] != 0; /* :888-890 */
+                c->bCbf[1] = sum[1] != 0;
+                c->bCbf[2] = sum[2] != 0;
+                xWriteCU(h, 0, (UInt)(cy == ncy - 1 && cx == ncx - 1)); /* Stage 4, :928 */
+                xEncCacheStoreCU(h, (UInt)x0, (UInt)y0);               /* Stage 5a, :931 */
+                xEncCacheUpdate(h, 0, 0, (UInt)cu, (UInt)cu);          /* Stage 5b, :934-935 */
+                c->uiOffset += cu;
+            }
+        }
+        if (bad) break;
+        xCabacFlush(&h->cabac, pBS);
+        xWriteSliceEnd(h);
+        X265_Frame tmp = h->refn[MAX_REF_NUM]; /* :965-970 */
+        for (int i = MAX_REF_NUM; i > 0; i--) h->refn[i] = h->refn[i - 1];
+        h->refn[0] = tmp;
+        const Int32 nb = xBitFlush(pBS);
+        bytes_out[f] = nb;
+        if (pos + nb <= bs_cap) memcpy(bs_out + pos, buf, nb);
+        pos += nb;
+    }
+    free(buf);
+    xEncFree(h);
+    return bad ? -2 : pos;
 }
 
 } /* extern "C" */

@@ -679,3 +679,28 @@ def test_intra_frame_vs_oracle(gpu, oracle, w, h, cu, qp):
         ncx = w // cu
         sums = np.abs(lv[:w * h].reshape(h // cu, cu, ncx, cu).astype(np.int64)).sum(axis=(1, 3)).ravel()
         np.testing.assert_array_equal(host(o["abs_sum_y"]).astype(np.int64), sums)
+
+
+def test_reference_bitstream_writer_over_gpu_intra_frames(gpu, reference):
+    """The drop-in claim for intra pictures, end to end: the GPU computes the whole pixel path of all eight frames
+    of BASELINE configs[0] (x265amd_intra_encode_frame: modes, levels, reconstruction), the REFERENCE's own bitstream
+    writer (headers, most-probable-mode derivation, xWriteCU, CABAC; oracle/ref_shim.cpp ref_write_intra_frames =
+    INTEGRATION.md's recipe) consumes them -- and the stream is the fixture's, byte for byte.  Needs oracle/_ref."""
+    import hashlib, json, os
+    from conftest import GOLDEN
+    from x265_amd import synth
+    with open(os.path.join(GOLDEN, "intra_cfg1.json")) as f:
+        doc = json.load(f)
+    w, h, cu, qp, nf = doc["width"], doc["height"], doc["cu"], doc["qp"], doc["frames"]
+    yuv = synth.make_intra_probe(w, h, nf)
+    rec, lvl, my, mc = [], [], [], []
+    for fr in range(nf):
+        y, u, v = _planes_of(yuv[fr], w, h)
+        o = gpu.intra_encode_frame(dev(y), dev(u), dev(v), cu, qp)
+        rec.append(np.concatenate([host(o["rec_y"]).ravel(), host(o["rec_u"]).ravel(), host(o["rec_v"]).ravel()]))
+        lvl.append(np.concatenate([host(o["level_y"]).ravel(), host(o["level_u"]).ravel(), host(o["level_v"]).ravel()]))
+        my.append(host(o["mode_y"]))
+        mc.append(host(o["mode_c"]))
+    nbytes, bs = reference.write_intra_frames(yuv, w, h, cu, qp, np.stack(rec), np.stack(lvl), np.stack(my), np.stack(mc))
+    assert [int(x) for x in nbytes] == doc["bytes_per_frame"]
+    assert hashlib.md5(bs.tobytes()).hexdigest() == doc["bitstream_md5"]

@@ -163,3 +163,21 @@ def test_intra_frame_restatement_vs_reference_encoder(oracle, reference, w, h, c
     for fr in range(3):
         orec, my, mc, lv = oracle.intra_encode_frame(yuv[fr], w, h, cu, qp, want_levels=True)
         np.testing.assert_array_equal(orec, rec[fr], f"frame {fr}")
+
+
+def test_reference_bitstream_writer_over_restated_pixel_path(oracle, reference):
+    """INTEGRATION.md's recipe for intra pictures, with the restatement in the GPU's place: the reference's own
+    headers / xEncIntraLoadRef (most probable modes) / xWriteCU / cache updates (ref_write_intra_frames) fed with
+    the frame-level results of orc_intra_encode_frame give BASELINE configs[0]'s bitstream, byte for byte."""
+    import hashlib, json, os
+    from conftest import GOLDEN
+    from x265_amd import synth
+    with open(os.path.join(GOLDEN, "intra_cfg1.json")) as f:
+        doc = json.load(f)
+    w, h, cu, qp, nf = doc["width"], doc["height"], doc["cu"], doc["qp"], doc["frames"]
+    yuv = synth.make_intra_probe(w, h, nf)
+    out = [oracle.intra_encode_frame(yuv[f], w, h, cu, qp, want_levels=True) for f in range(nf)]
+    nbytes, bs = reference.write_intra_frames(yuv, w, h, cu, qp, np.stack([o[0] for o in out]), np.stack([o[3] for o in out]),
+                                              np.stack([o[1] for o in out]), np.stack([o[2] for o in out]))
+    assert [int(x) for x in nbytes] == doc["bytes_per_frame"]
+    assert hashlib.md5(bs.tobytes()).hexdigest() == doc["bitstream_md5"]
