@@ -251,8 +251,27 @@ class IntraEncoder {
         check(x265amd_stream_sync(stream_), "x265amd_stream_sync");
     }
 
+    // The picture's bitstream from what fetch() brought back (Stage 4 of the reference's loop plus its headers and
+    // slice end: x265amd_intra_write_picture, host code).  Pictures are numbered in the order they are written:
+    // the first one is the IDR picture (src/encode.cpp:624,660).  Appends to `out`, returns the bytes added.
+    size_t write_picture(const int16_t *level, const uint8_t *mode_y, const uint8_t *mode_c, std::vector<uint8_t> &out)
+    {
+        x265amd_intra_syntax s{};
+        s.width = w_, s.height = h_, s.cu = cu_, s.qp = qp_, s.poc = poc_;
+        s.stride_y = w_, s.stride_c = w_ / 2;
+        s.level_y = level, s.level_u = level + ysz_, s.level_v = level + ysz_ + csz_;
+        s.mode_y = mode_y, s.mode_c = mode_c;
+        const size_t at = out.size();
+        out.resize(at + x265amd_intra_stream_bound(w_, h_));
+        size_t n = 0;
+        check(x265amd_intra_write_picture(&s, out.data() + at, out.size() - at, &n), "x265amd_intra_write_picture");
+        out.resize(at + n);
+        poc_++;
+        return n;
+    }
+
   private:
-    int w_, h_, cu_, qp_;
+    int w_, h_, cu_, qp_, poc_ = 0;
     void *stream_ = nullptr;
     size_t ysz_ = 0, csz_ = 0, fsz_ = 0, ncu_ = 0;
     std::unique_ptr<DeviceBuffer> src_, rec_, pred_, level_, mode_, sum_;

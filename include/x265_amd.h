@@ -59,6 +59,7 @@ enum {
     X265AMD_ERR_NOT_INIT = -4,  /* x265amd_init() not called */
     X265AMD_ERR_LDS = -5,       /* search window does not fit the 160 KiB LDS */
     X265AMD_ERR_WORKSPACE = -6, /* x265amd_me_fullsearch_sea_static: the job needs more than the static scratch */
+    X265AMD_ERR_BUFFER = -7,    /* x265amd_intra_write_picture: the output buffer is too small */
     X265AMD_ERR_HIP = -1000     /* -1000 - hipError_t */
 };
 
@@ -263,6 +264,27 @@ int x265amd_intra_waves(const x265amd_intra_frame *frame);
 int x265amd_intra_predict_wave(const x265amd_intra_frame *frame, int wave, void *stream);
 /* the whole frame: for every wave, x265amd_intra_predict_wave, then x265amd_tq_roundtrip of the three planes */
 int x265amd_intra_encode_frame(const x265amd_intra_frame *frame, void *stream);
+
+/* The syntax of one intra picture from what x265amd_intra_encode_frame left: HOST code, no GPU call, HOST pointers.
+ * Replaces, for that picture, everything xEncEncode writes (src/encode.cpp:626-662 start codes, SPS, PPS, slice
+ * header -- src/bitstream.cpp:112-295 --, xWriteCU per CU :474-585,928 with the residual coding of :270-461 and
+ * the CABAC engine of src/bitstream.cpp:526-828, xCabacFlush + xWriteSliceEnd :942-943), with xDefaultParams'
+ * settings (src/params.cpp:27-56), SLICE_I, no SEI.  The most probable modes come from mode_y as
+ * xEncIntraLoadRef derives them (:1268-1293), the coded-block flags from the levels.  Byte for byte the
+ * reference's stream when levels and modes are the reference's (tests: BASELINE configs[0]'s bitstream MD5).
+ *   poc: 0 for the first picture of the stream (an IDR slice), then 1, 2, ... (src/encode.cpp:624,660)
+ *   mode_c: the real chroma mode, as x265amd_intra_frame.d_mode_c holds it; X265AMD_ERR_ARG if it is not one of
+ *     the reference's candidates for the CU's luma mode (src/encode.cpp:781-793)
+ *   out / cap: receives the bytes; X265AMD_ERR_BUFFER if cap is too small (*bytes then holds the size needed);
+ *     x265amd_intra_stream_bound(width, height) is always enough. */
+typedef struct x265amd_intra_syntax {
+    int32_t width, height, cu, qp, poc;
+    int32_t stride_y, stride_c;                    /* of the level planes, in elements */
+    const int16_t *level_y, *level_u, *level_v;    /* picture geometry, as d_level_* */
+    const uint8_t *mode_y, *mode_c;                /* [ncus], raster order */
+} x265amd_intra_syntax;
+size_t x265amd_intra_stream_bound(int width, int height);
+int x265amd_intra_write_picture(const x265amd_intra_syntax *syntax, uint8_t *out, size_t cap, size_t *bytes);
 
 /* -------------------------------------------------------- transform/quant */
 

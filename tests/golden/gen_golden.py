@@ -247,6 +247,70 @@ def gen_intra_decide(ref):
     print("intra_decide.npz:", [m["key"] for m in meta])
 
 
+def random_syntax(rng, w, h, cu, nf, style):
+    """Levels and modes no encoder run produced -- every luma mode, every chroma candidate, empty blocks, lone
+    levels anywhere in a block, dense blocks, magnitudes up to the Int16 range (escape codes)."""
+    ncu = (w // cu) * (h // cu)
+    lv = np.zeros((nf, w * h * 3 // 2), np.int16)
+    my = rng.integers(0, 35, (nf, ncu)).astype(np.uint8)
+    mc = np.zeros((nf, ncu), np.uint8)
+    for f in range(nf):
+        for i in range(ncu):
+            cand = [0, 26, 10, 1, int(my[f, i])]          # src/encode.cpp:781-793 without LM
+            for k in range(4):
+                if cand[k] == my[f, i]:
+                    cand[k] = 34
+                    break
+            mc[f, i] = cand[int(rng.integers(0, 5))]
+        for pw, ph, n, off in ((w, h, cu, 0), (w // 2, h // 2, cu // 2, w * h), (w // 2, h // 2, cu // 2, w * h * 5 // 4)):
+            pl = np.zeros((ph, pw), np.int64)
+            for by in range(0, ph, n):
+                for bx in range(0, pw, n):
+                    r = rng.random()
+                    if r < 0.15:
+                        continue
+                    if r < 0.3:
+                        pl[by + rng.integers(0, n), bx + rng.integers(0, n)] = rng.integers(1, 4) * rng.choice([-1, 1])
+                        continue
+                    if style == "dense":
+                        mask = np.ones((n, n), bool)
+                    else:
+                        fall = np.exp(-np.add.outer(np.arange(n), np.arange(n)) / (1 + rng.random() * n))
+                        mask = rng.random((n, n)) < rng.random() * (1.0 if rng.random() < 0.2 else fall)
+                    big = rng.integers(-32767, 32768, (n, n)) if style == "tail" else rng.integers(-300, 301, (n, n))
+                    v = np.where(rng.random((n, n)) < (0.9 if style == "tail" else 0.6), rng.integers(-2, 3, (n, n)), big)
+                    if style == "ones":
+                        v = rng.choice([-1, 1], (n, n))
+                    pl[by:by + n, bx:bx + n] = np.where(mask, v, 0)
+            lv[f, off:off + pw * ph] = pl.ravel()
+    return lv, my, mc
+
+
+def gen_intra_stream(ref):
+    """Pins x265amd_intra_write_picture: (1) the reference's own writer (headers, xEncIntraLoadRef's most probable
+    modes, xWriteCU, CABAC: oracle/ref_shim.cpp ref_write_intra_frames) on random syntax; (2) a CU-32 encode of the
+    reference itself (416x224, QP 27, 2 frames of synth.make_intra_probe), as intra_cfg1.json is for CU 16."""
+    rng = np.random.default_rng(20240607)
+    out, meta = {}, []
+    for (w, h, cu, qp, nf, style) in ((64, 48, 16, 32, 3, "sparse"), (96, 64, 32, 20, 2, "sparse"), (48, 32, 16, 0, 2, "dense"),
+                                      (32, 32, 16, 22, 2, "tail"), (64, 64, 32, 51, 1, "ones"), (64, 32, 32, 37, 2, "tail")):
+        lv, my, mc = random_syntax(rng, w, h, cu, nf, style)
+        zero = np.zeros((nf, w * h * 3 // 2), np.uint8)
+        nbytes, bs = ref.write_intra_frames(zero, w, h, cu, qp, zero, lv, my, mc)
+        k = f"w{w}h{h}cu{cu}qp{qp}{style}"
+        out[k + "_levels"], out[k + "_mode_y"], out[k + "_mode_c"], out[k + "_bits"] = lv, my, mc, np.asarray(bs, np.uint8)
+        meta.append(dict(key=k, width=w, height=h, cu=cu, qp=qp, frames=nf, bytes_per_frame=[int(x) for x in nbytes]))
+    w, h, cu, qp, nf = 416, 224, 32, 27, 2
+    yuv = synth.make_intra_probe(w, h, nf)
+    rec, nbytes, md5, bs = ref.encode_intra(yuv, w, h, cu, qp)
+    enc = dict(width=w, height=h, cu=cu, qp=qp, frames=nf, input_md5=hashlib.md5(yuv.tobytes()).hexdigest(),
+               bytes_per_frame=[int(x) for x in nbytes], bitstream_md5=hashlib.md5(bs.tobytes()).hexdigest(),
+               recon_md5=[hashlib.md5(r.tobytes()).hexdigest() for r in rec])
+    out["meta"] = np.frombuffer(json.dumps(dict(random=meta, encode_cu32=enc)).encode(), np.uint8)
+    np.savez_compressed(os.path.join(HERE, "intra_stream.npz"), **out)
+    print("intra_stream.npz:", [m["key"] for m in meta], enc["bitstream_md5"])
+
+
 def main():
     pyoracle.build()
     ref = pyoracle.Reference()
@@ -255,6 +319,7 @@ def main():
     gen_tq_frame(ref)
     gen_intra_cfg1(ref)
     gen_intra_decide(ref)
+    gen_intra_stream(ref)
 
 
 if __name__ == "__main__":

@@ -108,9 +108,10 @@ def test_two_host_threads_share_one_device(gpu):
 
 @pytest.mark.gpu
 def test_cpp_host_intra_encoder_reconstruction_md5(gpu, oracle, tmp_path):
-    """host/encode_i.cpp (x265amd_host::IntraEncoder over x265amd_intra_encode_frame, plain g++, the C-ABI only) on
-    BASELINE configs[0]: the reconstruction file it writes has, frame by frame, the MD5s the reference encoder
-    printed (tests/golden/intra_cfg1.json); modes and levels equal the oracle's restatement of the loop."""
+    """host/encode_i.cpp (x265amd_host::IntraEncoder over x265amd_intra_encode_frame + x265amd_intra_write_picture,
+    plain g++, the C-ABI only) on BASELINE configs[0]: the reconstruction file it writes has, frame by frame, the
+    MD5s the reference encoder printed and the bitstream file has the MD5 of the reference's stream
+    (tests/golden/intra_cfg1.json); modes and levels equal the oracle's restatement of the loop."""
     import hashlib
     import json
     from x265_amd import synth
@@ -131,6 +132,10 @@ def test_cpp_host_intra_encoder_reconstruction_md5(gpu, oracle, tmp_path):
     modes = np.fromfile(prefix + ".modes", np.uint8).reshape(nf, 2, -1)
     for fr in range(nf):
         assert hashlib.md5(rec[fr].tobytes()).hexdigest() == doc["recon_md5"][fr], fr
+    # ... and the bitstream file is the reference's, byte for byte (IntraEncoder::write_picture)
+    bits = np.fromfile(prefix + ".bit", np.uint8)
+    assert len(bits) == sum(doc["bytes_per_frame"])
+    assert hashlib.md5(bits.tobytes()).hexdigest() == doc["bitstream_md5"]
     orec, my, mc, olv = oracle.intra_encode_frame(yuv[2], w, h, cu, qp, want_levels=True)
     np.testing.assert_array_equal(modes[2, 0], my)
     np.testing.assert_array_equal(modes[2, 1], mc)

@@ -704,3 +704,33 @@ def test_reference_bitstream_writer_over_gpu_intra_frames(gpu, reference):
     nbytes, bs = reference.write_intra_frames(yuv, w, h, cu, qp, np.stack(rec), np.stack(lvl), np.stack(my), np.stack(mc))
     assert [int(x) for x in nbytes] == doc["bytes_per_frame"]
     assert hashlib.md5(bs.tobytes()).hexdigest() == doc["bitstream_md5"]
+
+
+@pytest.mark.parametrize("which", ["cfg1", "cu32"])
+def test_gpu_intra_encoder_end_to_end_bitstream(gpu, which):
+    """The intra encoder with nothing of the reference or the oracle in it: x265amd_intra_encode_frame (GPU pixel
+    path) + x265amd_intra_write_picture (host syntax writer) on BASELINE configs[0] (CU 16) and on the CU-32
+    encode of tests/golden/intra_stream.npz -- bytes per frame, the MD5 of the stream and the MD5 of every
+    reconstruction are the ones the compiled reference produced."""
+    import hashlib, json, os
+    from conftest import GOLDEN, load_golden
+    from x265_amd import synth
+    if which == "cfg1":
+        with open(os.path.join(GOLDEN, "intra_cfg1.json")) as f:
+            doc = json.load(f)
+    else:
+        doc = load_golden("intra_stream.npz")[1]["encode_cu32"]
+    w, h, cu, qp, nf = doc["width"], doc["height"], doc["cu"], doc["qp"], doc["frames"]
+    yuv = synth.make_intra_probe(w, h, nf)
+    assert hashlib.md5(yuv.tobytes()).hexdigest() == doc["input_md5"]
+    nbytes, parts = [], []
+    for fr in range(nf):
+        y, u, v = _planes_of(yuv[fr], w, h)
+        o = gpu.intra_encode_frame(dev(y), dev(u), dev(v), cu, qp)
+        rec = np.concatenate([host(o["rec_y"]).ravel(), host(o["rec_u"]).ravel(), host(o["rec_v"]).ravel()])
+        assert hashlib.md5(rec.tobytes()).hexdigest() == doc["recon_md5"][fr], fr
+        bs = gpu.intra_write_picture(o["level_y"], o["level_u"], o["level_v"], o["mode_y"], o["mode_c"], cu, qp, fr)
+        nbytes.append(len(bs))
+        parts.append(bs)
+    assert nbytes == doc["bytes_per_frame"]
+    assert hashlib.md5(np.concatenate(parts).tobytes()).hexdigest() == doc["bitstream_md5"]

@@ -80,6 +80,8 @@ SIGNATURES = {
     "x265amd_intra_waves": (C.c_int, [C.c_void_p]),
     "x265amd_intra_predict_wave": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "x265amd_intra_encode_frame": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "x265amd_intra_stream_bound": (C.c_size_t, [C.c_int, C.c_int]),
+    "x265amd_intra_write_picture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
@@ -426,6 +428,40 @@ def intra_encode_frame(y, u, v, cu, qp, wave_by_wave=False, out=None):
                 tq_roundtrip({"y": y, "u": u, "v": v}[pl], o["pred_" + pl], tu_, q_, SLICE_I,
                              out=(o["level_" + pl], o["abs_sum_" + pl], o["rec_" + pl]))
     return o
+
+
+class IntraSyntax(C.Structure):
+    """include/x265_amd.h: x265amd_intra_syntax"""
+    _fields_ = ([(n, C.c_int32) for n in ("width", "height", "cu", "qp", "poc", "stride_y", "stride_c")] +
+                [(n, C.c_void_p) for n in ("level_y", "level_u", "level_v", "mode_y", "mode_c")])
+
+
+def intra_write_picture(level_y, level_u, level_v, mode_y, mode_c, cu, qp, poc):
+    """The bitstream of one intra picture (x265amd_intra_write_picture; host code): parameter sets, slice header, every
+    CU's syntax through CABAC, slice end -- the reference's bytes for these levels and modes.  Arguments are HOST
+    arrays (numpy, or CPU / CUDA tensors, which are brought over): int16 level planes [H][W], [H/2][W/2] x 2; uint8
+    modes [ncus] (mode_c = the real chroma mode).  Returns a uint8 numpy array."""
+    def host(a, dt):
+        if isinstance(a, torch.Tensor):
+            a = a.detach().cpu().numpy()
+        return np.ascontiguousarray(a, dtype=dt)
+    ly, lu, lv = host(level_y, np.int16), host(level_u, np.int16), host(level_v, np.int16)
+    my, mc = host(mode_y, np.uint8).ravel(), host(mode_c, np.uint8).ravel()
+    if ly.ndim != 2 or lu.ndim != 2 or lu.shape != lv.shape or lu.shape != (ly.shape[0] // 2, ly.shape[1] // 2):
+        raise ValueError("levels: need [H][W], [H/2][W/2], [H/2][W/2]")
+    h, w = ly.shape
+    ncus = (h // cu) * (w // cu) if cu in (16, 32) else 0
+    if my.size != ncus or mc.size != ncus:
+        raise ValueError("modes: need one luma and one chroma mode per CU")
+    d = IntraSyntax()
+    d.width, d.height, d.cu, d.qp, d.poc, d.stride_y, d.stride_c = w, h, cu, qp, poc, w, w // 2
+    d.level_y, d.level_u, d.level_v = ly.ctypes.data, lu.ctypes.data, lv.ctypes.data
+    d.mode_y, d.mode_c = my.ctypes.data, mc.ctypes.data
+    lib = _lib()
+    out = np.empty(lib.x265amd_intra_stream_bound(w, h), np.uint8)
+    n = C.c_size_t(0)
+    _check(lib.x265amd_intra_write_picture(C.byref(d), out.ctypes.data, out.size, C.byref(n)), "x265amd_intra_write_picture")
+    return out[:n.value].copy()
 
 
 def mv_to_numpy(mv):

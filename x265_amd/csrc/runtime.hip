@@ -80,6 +80,7 @@ extern "C" const char *x265amd_strerror(int status)
     case X265AMD_ERR_NOT_INIT: return "x265amd_init() has not been called for the current device";
     case X265AMD_ERR_LDS: return "search window does not fit in LDS";
     case X265AMD_ERR_WORKSPACE: return "job exceeds the static scratch of x265amd_me_fullsearch_sea_static; use x265amd_me_fullsearch_sea with a workspace";
+    case X265AMD_ERR_BUFFER: return "output buffer too small";
     default: break;
     }
     if (status <= X265AMD_ERR_HIP) return hipGetErrorString((hipError_t)(X265AMD_ERR_HIP - status));
