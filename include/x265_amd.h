@@ -264,6 +264,15 @@ int x265amd_intra_waves(const x265amd_intra_frame *frame);
 int x265amd_intra_predict_wave(const x265amd_intra_frame *frame, int wave, void *stream);
 /* the whole frame: for every wave, x265amd_intra_predict_wave, then x265amd_tq_roundtrip of the three planes */
 int x265amd_intra_encode_frame(const x265amd_intra_frame *frame, void *stream);
+/* A batch of independent intra frames (every frame of the reference is one: SLICE_I only, src/encode.cpp:491) in
+ * the same x265amd_intra_waves() steps: step d works on anti-diagonal d of every frame at once, which is how a
+ * picture whose anti-diagonals hold only a few dozen CUs fills 256 compute units.  `frame` describes frame 0; frame k
+ * uses every luma plane pointer + k * luma_frame_stride, every chroma plane pointer + k * chroma_frame_stride and
+ * every per-CU array + k * cu_frame_stride (strides in elements of the respective array; for 4:2:0 frame buffers
+ * stored one after the other both plane strides are width * height * 3 / 2).  Frames must not overlap
+ * (X265AMD_ERR_ARG); nframes <= 65535.  Same results as nframes calls of x265amd_intra_encode_frame. */
+int x265amd_intra_encode_frames(const x265amd_intra_frame *frame, int nframes, int64_t luma_frame_stride,
+                                int64_t chroma_frame_stride, int64_t cu_frame_stride, void *stream);
 
 /* The syntax of one intra picture from what x265amd_intra_encode_frame left: HOST code, no GPU call, HOST pointers.
  * Replaces, for that picture, everything xEncEncode writes (src/encode.cpp:626-662 start codes, SPS, PPS, slice

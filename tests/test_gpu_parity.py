@@ -734,3 +734,51 @@ def test_gpu_intra_encoder_end_to_end_bitstream(gpu, which):
         parts.append(bs)
     assert nbytes == doc["bytes_per_frame"]
     assert hashlib.md5(np.concatenate(parts).tobytes()).hexdigest() == doc["bitstream_md5"]
+
+
+def test_intra_frames_batch_cfg1(gpu):
+    """x265amd_intra_encode_frames: the eight frames of BASELINE configs[0] as ONE batch (anti-diagonal d of every
+    frame in one launch) -- every reconstruction has the reference's MD5, and the batch's levels and modes through the
+    syntax writer give the reference's bitstream."""
+    import hashlib, json, os
+    from conftest import GOLDEN
+    from x265_amd import synth
+    with open(os.path.join(GOLDEN, "intra_cfg1.json")) as f:
+        doc = json.load(f)
+    w, h, cu, qp, nf = doc["width"], doc["height"], doc["cu"], doc["qp"], doc["frames"]
+    yuv = synth.make_intra_probe(w, h, nf)
+    o = gpu.intra_encode_frames(dev(yuv), w, h, cu, qp)
+    rec, lvl, my, mc = host(o["rec"]), host(o["level"]), host(o["mode_y"]), host(o["mode_c"])
+    parts = []
+    for fr in range(nf):
+        assert hashlib.md5(rec[fr].tobytes()).hexdigest() == doc["recon_md5"][fr], fr
+        ly, lu, lv = lvl[fr, :w * h].reshape(h, w), lvl[fr, w * h:w * h * 5 // 4].reshape(h // 2, w // 2), lvl[fr, w * h * 5 // 4:].reshape(h // 2, w // 2)
+        parts.append(gpu.intra_write_picture(ly, lu, lv, my[fr], mc[fr], cu, qp, fr))
+    assert [len(p) for p in parts] == doc["bytes_per_frame"]
+    assert hashlib.md5(np.concatenate(parts).tobytes()).hexdigest() == doc["bitstream_md5"]
+
+
+@pytest.mark.parametrize("w,h,cu,qp,n", [(1920, 1088, 32, 30, 3), (416, 224, 32, 27, 5), (96, 64, 16, 45, 17), (32, 32, 32, 30, 2)])
+def test_intra_frames_batch_equals_single_frames(gpu, oracle, w, h, cu, qp, n):
+    """a batch == its frames one by one (x265amd_intra_encode_frame), on probe, noise and flat content; the small
+    geometries also against the oracle.  Reusing the output buffers of a first call changes nothing."""
+    from x265_amd import synth
+    rng = np.random.default_rng(w * 3 + h + n)
+    fsz = w * h * 3 // 2
+    yuv = np.stack([synth.make_intra_probe(w, h, n)[n - 1]] + [rng.integers(0, 256, fsz, dtype=np.uint8) for _ in range(n - 2)] +
+                   [np.full(fsz, 200, np.uint8)])
+    o = gpu.intra_encode_frames(dev(yuv), w, h, cu, qp)
+    o = gpu.intra_encode_frames(dev(yuv), w, h, cu, qp, out=o)
+    for fr in range(n):
+        y, u, v = _planes_of(yuv[fr], w, h)
+        s = gpu.intra_encode_frame(dev(y), dev(u), dev(v), cu, qp)
+        rec = np.concatenate([host(s["rec_y"]).ravel(), host(s["rec_u"]).ravel(), host(s["rec_v"]).ravel()])
+        lvl = np.concatenate([host(s["level_y"]).ravel(), host(s["level_u"]).ravel(), host(s["level_v"]).ravel()])
+        np.testing.assert_array_equal(host(o["rec"][fr]), rec)
+        np.testing.assert_array_equal(host(o["level"][fr]), lvl)
+        for k in ("mode_y", "mode_c", "cost_y", "cost_c", "abs_sum_y", "abs_sum_u", "abs_sum_v"):
+            np.testing.assert_array_equal(host(o[k][fr]), host(s[k]), k)
+        if w * h <= 416 * 224:
+            orec, my, mc, lv = oracle.intra_encode_frame(yuv[fr], w, h, cu, qp, want_levels=True)
+            np.testing.assert_array_equal(host(o["rec"][fr]), orec)
+            np.testing.assert_array_equal(host(o["level"][fr]), lv)

@@ -61,6 +61,22 @@ def main():
         print(f"{w}x{h} CU{cu}: {nw} anti-diagonals; eager {eager * 1e3:7.2f} ms/frame, graph replay {graph * 1e3:7.2f} ms/frame "
               f"({w * h / graph / 1e6:7.1f} Mpix/s); CPU restatement, one core {cpu * 1e3:8.1f} ms/frame; "
               f"identical to it: {np.array_equal(rec, orec) and np.array_equal(ref_rec, orec)}")
+        # a batch of independent frames per pass over the anti-diagonals (x265amd_intra_encode_frames)
+        for nb in (4, 8, 16, 32):
+            if nb * w * h * 3 // 2 * 5 > 6e9:
+                continue
+            seq = synth.make_intra_probe(w, h, min(nb, 8))
+            batch = torch.from_numpy(np.ascontiguousarray(np.resize(seq, (nb, w * h * 3 // 2)))).cuda()
+            o = gpu.intra_encode_frames(batch, w, h, cu, qp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                gpu.intra_encode_frames(batch, w, h, cu, qp, out=o)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 3
+            same = np.array_equal(o["rec"][0].cpu().numpy(), orec)
+            print(f"    batch of {nb:2d} frames: {dt * 1e3:7.2f} ms per batch = {dt / nb * 1e3:6.3f} ms/frame "
+                  f"({nb * w * h / dt / 1e6:8.1f} Mpix/s); frame 0 identical: {same}")
 
 
 if __name__ == "__main__":

@@ -80,6 +80,7 @@ SIGNATURES = {
     "x265amd_intra_waves": (C.c_int, [C.c_void_p]),
     "x265amd_intra_predict_wave": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "x265amd_intra_encode_frame": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "x265amd_intra_encode_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     "x265amd_intra_stream_bound": (C.c_size_t, [C.c_int, C.c_int]),
     "x265amd_intra_write_picture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -428,6 +429,40 @@ def intra_encode_frame(y, u, v, cu, qp, wave_by_wave=False, out=None):
                 tq_roundtrip({"y": y, "u": u, "v": v}[pl], o["pred_" + pl], tu_, q_, SLICE_I,
                              out=(o["level_" + pl], o["abs_sum_" + pl], o["rec_" + pl]))
     return o
+
+
+def intra_encode_frames(yuv, width, height, cu, qp, out=None):
+    """A batch of independent intra frames in one pass over the anti-diagonals (x265amd_intra_encode_frames).
+    yuv: uint8 [N][W*H*3/2] on the device, 4:2:0 frames Y,U,V one after the other (the reference's input format).
+    Returns a dict of batched outputs in the same layout: rec, pred (uint8 [N][W*H*3/2]), level (int16
+    [N][W*H*3/2]), mode_y / mode_c (uint8 [N][ncus]), cost_y / cost_c, abs_sum_y / _u / _v (int32 [N][ncus]).
+    out: the dict of an earlier call to reuse (nothing is allocated then)."""
+    _dev(yuv, torch.uint8, "yuv")
+    w, h = width, height
+    fsz = w * h * 3 // 2
+    if yuv.dim() != 2 or yuv.shape[1] != fsz or not yuv.is_contiguous():
+        raise ValueError("yuv: need a contiguous [N][W*H*3/2] tensor")
+    n = yuv.shape[0]
+    ncus = (h // cu) * (w // cu) if cu in (16, 32) else 0
+    dv = yuv.device
+    if out is None:
+        zi = lambda: torch.zeros((n, ncus), dtype=torch.int32, device=dv)
+        out = {"rec": torch.zeros((n, fsz), dtype=torch.uint8, device=dv), "pred": torch.zeros((n, fsz), dtype=torch.uint8, device=dv),
+               "level": torch.zeros((n, fsz), dtype=torch.int16, device=dv),
+               "mode_y": torch.zeros((n, ncus), dtype=torch.uint8, device=dv), "mode_c": torch.zeros((n, ncus), dtype=torch.uint8, device=dv),
+               "cost_y": zi(), "cost_c": zi(), "abs_sum_y": zi(), "abs_sum_u": zi(), "abs_sum_v": zi()}
+    f = IntraFrame()
+    f.width, f.height, f.cu, f.qp, f.stride_y, f.stride_c = w, h, cu, qp, w, w // 2
+    ysz, csz = w * h, w * h // 4
+    for name, t, esz in (("src", yuv, 1), ("rec", out["rec"], 1), ("pred", out["pred"], 1), ("level", out["level"], 2)):
+        base = t.data_ptr()
+        setattr(f, f"d_{name}_y", base)
+        setattr(f, f"d_{name}_u", base + esz * ysz)
+        setattr(f, f"d_{name}_v", base + esz * (ysz + csz))
+    for k in ("mode_y", "mode_c", "cost_y", "cost_c", "abs_sum_y", "abs_sum_u", "abs_sum_v"):
+        setattr(f, "d_" + k, out[k].data_ptr())
+    _check(_lib().x265amd_intra_encode_frames(C.byref(f), n, fsz, fsz, ncus, _stream()), "x265amd_intra_encode_frames")
+    return out
 
 
 class IntraSyntax(C.Structure):

@@ -243,6 +243,8 @@ struct IntraWave {
     int d;      // the anti-diagonal: CUs with cux + 2 cuy == d
     int cy_lo;  // smallest cuy on it
     uint32_t lambda;
+    int64_t fs_y, fs_c, fs_cu;  // a batch of independent frames (blockIdx.y): frame to frame, in elements, of the luma
+                                // planes, the chroma planes and the per-CU arrays
 };
 
 // sample i of the reference array of an n x n block at (x0, y0) of plane `rec`: xEncIntraLoadRef + xPaddingRef
@@ -278,7 +280,15 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
     constexpr int NC = N / 2, L2C = L2 - 1;
     constexpr int NPIX = N * N, PER = NPIX / 64;
     constexpr int NPIXC = NC * NC, PERC = NPIXC / 64;
-    const x265amd_intra_frame &f = w.f;
+    x265amd_intra_frame f = w.f;
+    {   // this workgroup's frame of the batch (block-uniform: scalar address arithmetic)
+        const int64_t oy = (int64_t)blockIdx.y * w.fs_y, oc = (int64_t)blockIdx.y * w.fs_c, ou = (int64_t)blockIdx.y * w.fs_cu;
+        f.d_src_y += oy, f.d_rec_y += oy, f.d_pred_y += oy;
+        f.d_src_u += oc, f.d_src_v += oc, f.d_rec_u += oc, f.d_rec_v += oc, f.d_pred_u += oc, f.d_pred_v += oc;
+        f.d_mode_y += ou, f.d_mode_c += ou;
+        if (f.d_cost_y) f.d_cost_y += ou;
+        if (f.d_cost_c) f.d_cost_c += ou;
+    }
     __shared__ uint8_t s_ref[2][kMaxRef + 3];
     __shared__ uint8_t s_refc[2][4 * 16 + 4];  // U, V: chroma reads the samples as they are
     __shared__ uint8_t s_main[NWAVES][2][kMainRow];
@@ -456,10 +466,16 @@ static int intra_frame_check(const x265amd_intra_frame *f)
     return X265AMD_OK;
 }
 
-static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st)
+struct IntraBatch {
+    int nframes;
+    int64_t fs_y, fs_c, fs_cu;
+};
+
+static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st, const IntraBatch &b = IntraBatch{1, 0, 0, 0})
 {
     IntraWave w;
     w.f = *f;
+    w.fs_y = b.fs_y, w.fs_c = b.fs_c, w.fs_cu = b.fs_cu;
     w.ncx = f->width / f->cu;
     w.ncy = f->height / f->cu;
     w.d = d;
@@ -469,7 +485,7 @@ static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st
     const int hi = d / 2 < w.ncy - 1 ? d / 2 : w.ncy - 1;
     if (hi < lo) return X265AMD_OK;
     w.cy_lo = lo;
-    const dim3 grid((unsigned)(hi - lo + 1)), block(kWaveThreads);
+    const dim3 grid((unsigned)(hi - lo + 1), (unsigned)b.nframes), block(kWaveThreads);
     if (f->cu == 16)
         hipLaunchKernelGGL(intra_wave_kernel<16>, grid, block, 0, st, w);
     else
@@ -492,53 +508,88 @@ extern "C" int x265amd_intra_predict_wave(const x265amd_intra_frame *f, int wave
     return intra_wave_launch(f, wave, (hipStream_t)stream);
 }
 
-extern "C" int x265amd_intra_encode_frame(const x265amd_intra_frame *f, void *stream)
+// one frame, or a batch of independent frames whose planes lie at fixed distances from the first frame's
+static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipStream_t stream)
 {
-    if (!initialised()) return X265AMD_ERR_NOT_INIT;
-    int rc = intra_frame_check(f);
-    if (rc != X265AMD_OK) return rc;
     // the transform stage of a wave: forward + inverse of the three planes (Stage 3a / 3b, src/encode.cpp:863-925)
     // over the 128 x 32 pixel tile units that hold the wave's CUs (the whole plane where the matrix-core kernel does
     // not apply) -- TUs of earlier waves that share a unit come out as they already are (same source, same
     // prediction), TUs of later waves are overwritten when their wave comes
     x265amd_tq_desc ty = {}, tu = {}, tv = {};
-    ty.width = f->width, ty.height = f->height, ty.tu = f->cu, ty.qp = f->qp, ty.slice_type = X265AMD_SLICE_I, ty.nframes = 1;
+    ty.width = f->width, ty.height = f->height, ty.tu = f->cu, ty.qp = f->qp, ty.slice_type = X265AMD_SLICE_I, ty.nframes = b.nframes;
     ty.d_src = f->d_src_y, ty.src_stride = f->stride_y;
     ty.d_pred = f->d_pred_y, ty.pred_stride = f->stride_y;
     ty.d_level = f->d_level_y, ty.level_stride = f->stride_y;
     ty.d_rec = f->d_rec_y, ty.rec_stride = f->stride_y;
     ty.d_abs_sum = f->d_abs_sum_y;
+    ty.src_frame_stride = ty.pred_frame_stride = ty.rec_frame_stride = ty.level_frame_stride = b.fs_y;
+    ty.abs_sum_frame_stride = b.fs_cu;
     tu.width = f->width / 2, tu.height = f->height / 2, tu.tu = f->cu / 2, tu.qp = x265amd_chroma_qp(f->qp);
-    tu.slice_type = X265AMD_SLICE_I, tu.nframes = 1;
+    tu.slice_type = X265AMD_SLICE_I, tu.nframes = b.nframes;
     tu.src_stride = tu.pred_stride = tu.level_stride = tu.rec_stride = f->stride_c;
+    tu.src_frame_stride = tu.pred_frame_stride = tu.rec_frame_stride = tu.level_frame_stride = b.fs_c;
+    tu.abs_sum_frame_stride = b.fs_cu;
     tv = tu;
     tu.d_src = f->d_src_u, tu.d_pred = f->d_pred_u, tu.d_level = f->d_level_u, tu.d_rec = f->d_rec_u, tu.d_abs_sum = f->d_abs_sum_u;
     tv.d_src = f->d_src_v, tv.d_pred = f->d_pred_v, tv.d_level = f->d_level_v, tv.d_rec = f->d_rec_v, tv.d_abs_sum = f->d_abs_sum_v;
-    // U and V in one launch (a batch of two planes) when the four V planes sit at one common distance behind
-    // their U planes, as they do in a 4:2:0 frame buffer
+    // U and V in one launch (one batch of planes) when all V planes continue the U planes' progression: a single
+    // frame whose four V planes sit at one common distance behind their U planes (a 4:2:0 frame buffer), or a batch
+    // stored plane-major (all U planes, then all V planes, one stride)
     const int64_t du = f->d_src_v - f->d_src_u;
-    const bool both = du > 0 && f->d_pred_v - f->d_pred_u == du && f->d_rec_v - f->d_rec_u == du &&
-                      f->d_level_v - f->d_level_u == du && du >= (int64_t)tu.height * f->stride_c &&
-                      (!f->d_abs_sum_u == !f->d_abs_sum_v) &&
-                      (!f->d_abs_sum_u || f->d_abs_sum_v - f->d_abs_sum_u >= (int64_t)(tu.height / tu.tu) * (tu.width / tu.tu));
-    if (both) {
-        tu.nframes = 2;
-        tu.src_frame_stride = tu.pred_frame_stride = tu.rec_frame_stride = tu.level_frame_stride = du;
-        tu.abs_sum_frame_stride = f->d_abs_sum_u ? f->d_abs_sum_v - f->d_abs_sum_u : 0;
+    const int64_t nu = (int64_t)(tu.height / tu.tu) * (tu.width / tu.tu);
+    bool both = du > 0 && f->d_pred_v - f->d_pred_u == du && f->d_rec_v - f->d_rec_u == du &&
+                f->d_level_v - f->d_level_u == du && du >= (int64_t)tu.height * f->stride_c &&
+                (!f->d_abs_sum_u == !f->d_abs_sum_v);
+    if (both && b.nframes == 1) {
+        both = !f->d_abs_sum_u || f->d_abs_sum_v - f->d_abs_sum_u >= nu;
+        if (both) {
+            tu.nframes = 2;
+            tu.src_frame_stride = tu.pred_frame_stride = tu.rec_frame_stride = tu.level_frame_stride = du;
+            tu.abs_sum_frame_stride = f->d_abs_sum_u ? f->d_abs_sum_v - f->d_abs_sum_u : 0;
+        }
+    } else if (both) {
+        both = du == (int64_t)b.nframes * b.fs_c && (!f->d_abs_sum_u || f->d_abs_sum_v - f->d_abs_sum_u == (int64_t)b.nframes * b.fs_cu);
+        if (both) tu.nframes = 2 * b.nframes;
     }
     const int nw = x265amd_intra_waves(f);
     const int ncx = f->width / f->cu, ncy = f->height / f->cu;
     const int l2 = f->cu == 16 ? 4 : 5;
     for (int d = 0; d < nw; d++) {
-        rc = intra_wave_launch(f, d, (hipStream_t)stream);
+        int rc = intra_wave_launch(f, d, stream, b);
         // the transform stage follows the diagonal: only the tile units that hold its CUs
         const int lo = d - (ncx - 1) > 0 ? (d - (ncx - 1) + 1) / 2 : 0;
         const int hi = d / 2 < ncy - 1 ? d / 2 : ncy - 1;
         const TqDiag dy{hi - lo + 1, d, lo, l2}, dc{hi - lo + 1, d, lo, l2 - 1};
-        if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&ty, dy, (hipStream_t)stream);
-        if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&tu, dc, (hipStream_t)stream);
-        if (rc == X265AMD_OK && !both) rc = tq_roundtrip_diag(&tv, dc, (hipStream_t)stream);
+        if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&ty, dy, stream);
+        if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&tu, dc, stream);
+        if (rc == X265AMD_OK && !both) rc = tq_roundtrip_diag(&tv, dc, stream);
         if (rc != X265AMD_OK) return rc;
     }
     return X265AMD_OK;
+}
+
+extern "C" int x265amd_intra_encode_frame(const x265amd_intra_frame *f, void *stream)
+{
+    if (!initialised()) return X265AMD_ERR_NOT_INIT;
+    const int rc = intra_frame_check(f);
+    if (rc != X265AMD_OK) return rc;
+    return intra_encode(f, IntraBatch{1, 0, 0, 0}, (hipStream_t)stream);
+}
+
+extern "C" int x265amd_intra_encode_frames(const x265amd_intra_frame *f, int nframes, int64_t luma_frame_stride,
+                                           int64_t chroma_frame_stride, int64_t cu_frame_stride, void *stream)
+{
+    if (!initialised()) return X265AMD_ERR_NOT_INIT;
+    const int rc = intra_frame_check(f);
+    if (rc != X265AMD_OK) return rc;
+    if (nframes < 0 || nframes > 65535) return X265AMD_ERR_ARG;  // frames are the grid's y dimension
+    if (nframes == 0) return X265AMD_OK;
+    if (nframes > 1) {
+        // a frame's planes must end before the next frame's begin (outputs of different frames never alias)
+        const int64_t need_y = (int64_t)(f->height - 1) * f->stride_y + f->width;
+        const int64_t need_c = (int64_t)(f->height / 2 - 1) * f->stride_c + f->width / 2;
+        const int64_t ncus = (int64_t)(f->width / f->cu) * (f->height / f->cu);
+        if (luma_frame_stride < need_y || chroma_frame_stride < need_c || cu_frame_stride < ncus) return X265AMD_ERR_ARG;
+    }
+    return intra_encode(f, IntraBatch{nframes, luma_frame_stride, chroma_frame_stride, cu_frame_stride}, (hipStream_t)stream);
 }
