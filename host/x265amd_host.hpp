@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <memory>
 #include <utility>
 #include <vector>
@@ -202,52 +203,62 @@ class GopEncoder {
 // reference takes its MD5 SEI (src/encode.cpp:945-950).
 class IntraEncoder {
   public:
-    IntraEncoder(int width, int height, int cu, int qp, int device = 0, void *stream = nullptr)
-        : w_(width), h_(height), cu_(cu), qp_(qp), stream_(stream)
+    // `batch`: how many independent frames one encode() may take (they share every anti-diagonal step on the GPU:
+    // x265amd_intra_encode_frames); the device planes are allocated for that many.
+    IntraEncoder(int width, int height, int cu, int qp, int device = 0, void *stream = nullptr, int batch = 1)
+        : w_(width), h_(height), cu_(cu), qp_(qp), batch_(batch), stream_(stream)
     {
-        if (width <= 0 || height <= 0 || (cu != 16 && cu != 32) || width % cu || height % cu)  // src/params.cpp:73-77
+        if (width <= 0 || height <= 0 || (cu != 16 && cu != 32) || width % cu || height % cu || batch < 1)  // src/params.cpp:73-77
             throw Error(X265AMD_ERR_ARG, "IntraEncoder: CU 16 or 32, width and height multiples of it");
         check(x265amd_init(device), "x265amd_init");
         ysz_ = (size_t)width * height;
         csz_ = ysz_ / 4;
         fsz_ = ysz_ + 2 * csz_;
         ncu_ = (size_t)(width / cu) * (height / cu);
-        src_.reset(new DeviceBuffer(fsz_));
-        rec_.reset(new DeviceBuffer(fsz_));
-        pred_.reset(new DeviceBuffer(fsz_));
-        level_.reset(new DeviceBuffer(2 * fsz_));
-        mode_.reset(new DeviceBuffer(2 * ncu_));
-        sum_.reset(new DeviceBuffer(4 * 3 * ncu_));
+        const size_t nb = (size_t)batch;
+        src_.reset(new DeviceBuffer(fsz_ * nb));
+        rec_.reset(new DeviceBuffer(fsz_ * nb));
+        pred_.reset(new DeviceBuffer(fsz_ * nb));
+        level_.reset(new DeviceBuffer(2 * fsz_ * nb));
+        mode_.reset(new DeviceBuffer(2 * ncu_ * nb));      // [luma, chroma][batch][ncu]
+        sum_.reset(new DeviceBuffer(4 * 3 * ncu_ * nb));   // [Y, U, V][batch][ncu]
         f_ = x265amd_intra_frame{};
         f_.width = width, f_.height = height, f_.cu = cu, f_.qp = qp, f_.stride_y = width, f_.stride_c = width / 2;
         f_.d_src_y = src_->as(), f_.d_src_u = src_->as(ysz_), f_.d_src_v = src_->as(ysz_ + csz_);
         f_.d_rec_y = rec_->as(), f_.d_rec_u = rec_->as(ysz_), f_.d_rec_v = rec_->as(ysz_ + csz_);
         f_.d_pred_y = pred_->as(), f_.d_pred_u = pred_->as(ysz_), f_.d_pred_v = pred_->as(ysz_ + csz_);
         f_.d_level_y = level_->as<int16_t>(), f_.d_level_u = level_->as<int16_t>(2 * ysz_), f_.d_level_v = level_->as<int16_t>(2 * (ysz_ + csz_));
-        f_.d_mode_y = mode_->as(), f_.d_mode_c = mode_->as(ncu_);
-        f_.d_abs_sum_y = sum_->as<uint32_t>(), f_.d_abs_sum_u = sum_->as<uint32_t>(4 * ncu_), f_.d_abs_sum_v = sum_->as<uint32_t>(8 * ncu_);
+        f_.d_mode_y = mode_->as(), f_.d_mode_c = mode_->as(ncu_ * nb);
+        f_.d_abs_sum_y = sum_->as<uint32_t>(), f_.d_abs_sum_u = sum_->as<uint32_t>(4 * ncu_ * nb), f_.d_abs_sum_v = sum_->as<uint32_t>(8 * ncu_ * nb);
     }
 
     size_t frame_bytes() const { return fsz_; }
     size_t cus() const { return ncu_; }
+    int batch() const { return batch_; }
     int waves() const { return x265amd_intra_waves(&f_); }
 
-    // One frame, Y,U,V each (the reference's input format).  Asynchronous; fetch() waits.
-    void encode(const uint8_t *yuv)
+    // n <= batch frames, Y,U,V each, one after the other (the reference's input format).  Asynchronous; fetch() waits.
+    void encode(const uint8_t *yuv, int n = 1)
     {
-        check(x265amd_memcpy_h2d(src_->as(), yuv, fsz_, stream_), "x265amd_memcpy_h2d");
-        check(x265amd_intra_encode_frame(&f_, stream_), "x265amd_intra_encode_frame");
+        if (n < 1 || n > batch_) throw Error(X265AMD_ERR_ARG, "IntraEncoder::encode: more frames than the batch holds");
+        check(x265amd_memcpy_h2d(src_->as(), yuv, fsz_ * n, stream_), "x265amd_memcpy_h2d");
+        check(x265amd_intra_encode_frames(&f_, n, (int64_t)fsz_, (int64_t)fsz_, (int64_t)ncu_, stream_), "x265amd_intra_encode_frames");
     }
 
-    // reconstruction [W*H*3/2], levels [W*H*3/2] (Y,U,V like the picture), luma / chroma mode per CU, xQuant's
-    // sums [3][ncu] (what sets bCbf, src/encode.cpp:888-890).  Null pointers are skipped.
-    void fetch(uint8_t *rec, int16_t *level, uint8_t *mode_y, uint8_t *mode_c, uint32_t *abs_sum = nullptr)
+    // of the n frames last encoded: reconstruction [n][W*H*3/2], levels [n][W*H*3/2] (Y,U,V like the picture), luma /
+    // chroma mode per CU [n][ncu] each, xQuant's sums [3][n][ncu] (what sets bCbf, src/encode.cpp:888-890).  Null
+    // pointers are skipped.
+    void fetch(uint8_t *rec, int16_t *level, uint8_t *mode_y, uint8_t *mode_c, uint32_t *abs_sum = nullptr, int n = 1)
     {
-        if (rec) check(x265amd_memcpy_d2h(rec, rec_->as(), fsz_, stream_), "x265amd_memcpy_d2h");
-        if (level) check(x265amd_memcpy_d2h(level, level_->as(), 2 * fsz_, stream_), "x265amd_memcpy_d2h");
-        if (mode_y) check(x265amd_memcpy_d2h(mode_y, mode_->as(), ncu_, stream_), "x265amd_memcpy_d2h");
-        if (mode_c) check(x265amd_memcpy_d2h(mode_c, mode_->as(ncu_), ncu_, stream_), "x265amd_memcpy_d2h");
-        if (abs_sum) check(x265amd_memcpy_d2h(abs_sum, sum_->as(), 12 * ncu_, stream_), "x265amd_memcpy_d2h");
+        if (n < 1 || n > batch_) throw Error(X265AMD_ERR_ARG, "IntraEncoder::fetch: more frames than the batch holds");
+        const size_t nb = (size_t)batch_;
+        if (rec) check(x265amd_memcpy_d2h(rec, rec_->as(), fsz_ * n, stream_), "x265amd_memcpy_d2h");
+        if (level) check(x265amd_memcpy_d2h(level, level_->as(), 2 * fsz_ * n, stream_), "x265amd_memcpy_d2h");
+        if (mode_y) check(x265amd_memcpy_d2h(mode_y, mode_->as(), ncu_ * n, stream_), "x265amd_memcpy_d2h");
+        if (mode_c) check(x265amd_memcpy_d2h(mode_c, mode_->as(ncu_ * nb), ncu_ * n, stream_), "x265amd_memcpy_d2h");
+        if (abs_sum)
+            for (int pl = 0; pl < 3; pl++)
+                check(x265amd_memcpy_d2h(abs_sum + (size_t)pl * n * ncu_, sum_->as(4 * ncu_ * nb * pl), 4 * ncu_ * n, stream_), "x265amd_memcpy_d2h");
         check(x265amd_stream_sync(stream_), "x265amd_stream_sync");
     }
 
@@ -256,8 +267,41 @@ class IntraEncoder {
     // the first one is the IDR picture (src/encode.cpp:624,660).  Appends to `out`, returns the bytes added.
     size_t write_picture(const int16_t *level, const uint8_t *mode_y, const uint8_t *mode_c, std::vector<uint8_t> &out)
     {
+        return write_at(poc_++, level, mode_y, mode_c, out);
+    }
+
+    // n pictures (fetch()'s layout) on up to `threads` host threads -- every picture is a slice of its own with a fresh
+    // arithmetic-coder state, so they are written independently; out[k] receives picture k.
+    void write_pictures(const int16_t *level, const uint8_t *mode_y, const uint8_t *mode_c, int n, int threads,
+                        std::vector<std::vector<uint8_t>> &out)
+    {
+        out.assign((size_t)n, {});
+        const int first = poc_;
+        poc_ += n;
+        const int nt = threads < 1 ? 1 : threads > n ? n : threads;
+        std::vector<std::thread> pool;
+        std::vector<std::string> errors((size_t)nt);
+        std::vector<int> status((size_t)nt, X265AMD_OK);
+        for (int t = 0; t < nt; t++)
+            pool.emplace_back([&, t] {
+                try {
+                    for (int k = t; k < n; k += nt)
+                        write_at(first + k, level + (size_t)k * fsz_, mode_y + (size_t)k * ncu_, mode_c + (size_t)k * ncu_, out[(size_t)k]);
+                } catch (const Error &e) {
+                    status[(size_t)t] = e.status;
+                    errors[(size_t)t] = e.what();
+                }
+            });
+        for (auto &th : pool) th.join();
+        for (int t = 0; t < nt; t++)
+            if (status[(size_t)t] != X265AMD_OK) throw Error(status[(size_t)t], "IntraEncoder::write_pictures");
+    }
+
+  private:
+    size_t write_at(int poc, const int16_t *level, const uint8_t *mode_y, const uint8_t *mode_c, std::vector<uint8_t> &out) const
+    {
         x265amd_intra_syntax s{};
-        s.width = w_, s.height = h_, s.cu = cu_, s.qp = qp_, s.poc = poc_;
+        s.width = w_, s.height = h_, s.cu = cu_, s.qp = qp_, s.poc = poc;
         s.stride_y = w_, s.stride_c = w_ / 2;
         s.level_y = level, s.level_u = level + ysz_, s.level_v = level + ysz_ + csz_;
         s.mode_y = mode_y, s.mode_c = mode_c;
@@ -266,12 +310,10 @@ class IntraEncoder {
         size_t n = 0;
         check(x265amd_intra_write_picture(&s, out.data() + at, out.size() - at, &n), "x265amd_intra_write_picture");
         out.resize(at + n);
-        poc_++;
         return n;
     }
 
-  private:
-    int w_, h_, cu_, qp_, poc_ = 0;
+    int w_, h_, cu_, qp_, batch_, poc_ = 0;
     void *stream_ = nullptr;
     size_t ysz_ = 0, csz_ = 0, fsz_ = 0, ncu_ = 0;
     std::unique_ptr<DeviceBuffer> src_, rec_, pred_, level_, mode_, sum_;

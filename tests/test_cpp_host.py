@@ -140,6 +140,13 @@ def test_cpp_host_intra_encoder_reconstruction_md5(gpu, oracle, tmp_path):
     np.testing.assert_array_equal(modes[2, 0], my)
     np.testing.assert_array_equal(modes[2, 1], mc)
     np.testing.assert_array_equal(lvl[2], olv)
+    # batches of three frames through the GPU, four writer threads: the same four files
+    prefix2 = str(tmp_path / "out_b3")
+    r = subprocess.run([exe, str(src), str(w), str(h), str(nf), str(cu), str(qp), prefix2, "3", "4"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for ext in (".rec", ".lvl", ".modes", ".bit"):
+        with open(prefix + ext, "rb") as fa, open(prefix2 + ext, "rb") as fb:
+            assert fa.read() == fb.read(), ext
     # geometry the reference rejects (src/params.cpp:73-77) comes back as an error, not a crash
     r = subprocess.run([exe, str(src), "100", "64", "1", "16", "30", prefix], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3 and "IntraEncoder" in r.stderr

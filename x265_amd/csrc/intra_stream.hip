@@ -43,6 +43,13 @@ public:
             }
         }
     }
+    void byte(uint32_t b)  // eight bits at once; the arithmetic coder's output is always byte-aligned
+    {
+        if (fill_ == 0)
+            escaped((uint8_t)b);
+        else
+            bits(b & 0xffu, 8);
+    }
     void flag(uint32_t b) { bits(b & 1u, 1); }
     void ue(uint32_t v)  // Exp-Golomb, xWriteUvlc (inc/bitstream.h:134-140)
     {
@@ -234,12 +241,12 @@ public:
     void finish()  // xCabacFlush
     {
         if (low_ >> (32 - left_)) {
-            out_.bits((uint32_t)held_ + 1u, 8);
-            for (; run_ > 1; run_--) out_.bits(0x00, 8);
+            out_.byte((uint32_t)held_ + 1u);
+            for (; run_ > 1; run_--) out_.byte(0x00);
             low_ -= 1u << (32 - left_);
         } else {
-            if (run_ > 0) out_.bits(held_, 8);
-            for (; run_ > 1; run_--) out_.bits(0xff, 8);
+            if (run_ > 0) out_.byte(held_);
+            for (; run_ > 1; run_--) out_.byte(0xff);
         }
         out_.bits(low_ >> 8, 24 - left_);
     }
@@ -257,9 +264,9 @@ private:
                 run_++;
             } else if (run_ > 0) {
                 const uint32_t carry = lead >> 8;
-                out_.bits((held_ + carry) & 0xffu, 8);
+                out_.byte((held_ + carry) & 0xffu);
                 held_ = (uint8_t)lead;
-                for (; run_ > 1; run_--) out_.bits((0xffu + carry) & 0xffu, 8);
+                for (; run_ > 1; run_--) out_.byte((0xffu + carry) & 0xffu);
             } else {
                 run_ = 1;
                 held_ = (uint8_t)lead;
@@ -314,29 +321,59 @@ int last_group(int pos)
 }
 int group_first(int g) { return g < 4 ? g : (1 << (g >> 1)) + (g & 1) * (1 << ((g >> 1) - 1)); }
 
+// Where a block's levels are: one pass over its rows, four levels (one 64-bit load) at a time.  row[y] has bit x set
+// where level (x, y) is not zero -- two empty rows follow the block and no bit is set at or beyond x = N, so the
+// neighbourhood tests of the significance contexts need no edge cases; has[] flags the 4x4 groups that hold a level.
+struct BlockMap {
+    uint32_t row[34];
+    uint8_t has[64];
+    bool any;
+    void scan(const int16_t *blk, int stride, int n)
+    {
+        const int side = n >> 2;
+        any = false;
+        row[n] = row[n + 1] = 0;
+        for (int gy = 0; gy < side; gy++) {
+            uint32_t r[4] = {0, 0, 0, 0};
+            for (int gx = 0; gx < side; gx++) {
+                uint32_t in_group = 0;
+                for (int k = 0; k < 4; k++) {
+                    uint64_t q;
+                    memcpy(&q, blk + (4 * gy + k) * stride + 4 * gx, 8);
+                    if (q) {
+                        const uint32_t m = (uint32_t)((q & 0xffffull) != 0) | (uint32_t)((q & 0xffff0000ull) != 0) << 1 |
+                                           (uint32_t)((q & 0xffff00000000ull) != 0) << 2 | (uint32_t)((q >> 48) != 0) << 3;
+                        r[k] |= m << (4 * gx);
+                        in_group |= m;
+                    }
+                }
+                has[gy * side + gx] = in_group != 0;
+                any |= in_group != 0;
+            }
+            for (int k = 0; k < 4; k++) row[4 * gy + k] = r[k];
+        }
+    }
+};
+
 class ResidualCoder {
 public:
     explicit ResidualCoder(Cabac &c) : c_(c) {}
 
-    // blk: top-left of the block in its plane, `stride` elements per row.  The block holds at least one level.
-    void code(const int16_t *blk, int stride, int n, bool luma)
+    // blk: top-left of the block in its plane, `stride` elements per row; m: its map (m.any is true)
+    void code(const int16_t *blk, int stride, int n, bool luma, BlockMap &m)
     {
         const int lg = n == 8 ? 3 : n == 16 ? 4 : 5, side = n >> 2;  // side: coefficient groups per row
         const Diag &groups = side == 2 ? kDiag2 : side == 4 ? kDiag4 : kDiag8;
-        auto at = [&](int x, int y) -> int { return blk[y * stride + x]; };
+        uint8_t *has = m.has;
 
-        // which 4x4 groups hold a level, and the last level in coding order (group by group along the diagonal
-        // order of the groups, diagonal order inside each: ausScanIdx8/16/32[SCAN_DIAG])
-        uint8_t has[64] = {0};
-        int last_set = -1, last_in = 0;
-        for (int s = 0; s < side * side; s++) {
-            const int gx = groups.x[s], gy = groups.y[s];
-            for (int i = 0; i < 16; i++)
-                if (at(4 * gx + kDiag4.x[i], 4 * gy + kDiag4.y[i])) {
-                    has[gy * side + gx] = 1;
-                    last_set = s;
-                    last_in = i;
-                }
+        // the last level in coding order (group by group along the diagonal order of the groups, diagonal order
+        // inside each: ausScanIdx8/16/32[SCAN_DIAG])
+        int last_set = side * side - 1;
+        while (!has[groups.y[last_set] * side + groups.x[last_set]]) last_set--;
+        int last_in = 15;
+        {
+            const int gx = groups.x[last_set], gy = groups.y[last_set];
+            while (!((m.row[4 * gy + kDiag4.y[last_in]] >> (4 * gx + kDiag4.x[last_in])) & 1u)) last_in--;
         }
         const int lx = 4 * groups.x[last_set] + kDiag4.x[last_in], ly = 4 * groups.y[last_set] + kDiag4.y[last_in];
         last_position(lx, ly, n, lg, luma);
@@ -348,8 +385,9 @@ public:
             uint32_t rice = 0, signs = 0;
             int mag[16], cnt = 0;
             int i = 15;  // next position of this group, in reverse coding order
+            const int16_t *g0 = blk + 4 * gy * stride + 4 * gx;
             if (s == last_set) {
-                const int v = at(lx, ly);
+                const int v = g0[kDiag4.y[last_in] * stride + kDiag4.x[last_in]];
                 mag[cnt++] = v < 0 ? -v : v;
                 signs = v < 0;
                 i = last_in - 1;
@@ -364,10 +402,10 @@ public:
             }
             if (has[gy * side + gx]) {
                 for (; i >= 0; i--) {
-                    const int x = 4 * gx + kDiag4.x[i], y = 4 * gy + kDiag4.y[i];
-                    const int v = at(x, y);
+                    const int dx = kDiag4.x[i], dy = kDiag4.y[i];
+                    const int v = g0[dy * stride + dx];
                     // the first position of a group that was flagged and has shown no level yet is known to hold one
-                    if (i != 0 || s == 0 || cnt) c_.bin(v != 0, sig0 + sig_ctx(blk, stride, x, y, n, lg, luma));
+                    if (i != 0 || s == 0 || cnt) c_.bin(v != 0, sig0 + sig_ctx(m.row, 4 * gx + dx, 4 * gy + dy, n, lg, luma));
                     if (v) {
                         mag[cnt++] = v < 0 ? -v : v;
                         signs = (signs << 1) + (v < 0);
@@ -430,8 +468,9 @@ private:
         }
     }
 
-    // getSigCtxInc (src/encode.cpp:111-190) for N = 8 (blockType 3) and N = 16, 32
-    static int sig_ctx(const int16_t *blk, int stride, int x, int y, int n, int lg, bool luma)
+    // getSigCtxInc (src/encode.cpp:111-190) for N = 8 (blockType 3) and N = 16, 32, on the block's bitmap: the
+    // reference's `x < width - 1`, `y < height - 1` ... guards are the map's empty margins
+    static int sig_ctx(const uint32_t *row, int x, int y, int n, int lg, bool luma)
     {
         if (lg == 3) {
             static const uint8_t map[16] = {0, 1, 2, 3, 4, 5, 6, 3, 8, 6, 6, 7, 9, 9, 7, 7};
@@ -441,17 +480,10 @@ private:
         const int off = luma ? 20 : 17;
         if (x + y == 0) return off;
         if ((x >> 2) + (y >> 2) >= 3 * (n >> 4)) return luma ? 24 : 18;
-        const int16_t *p = blk + y * stride + x;
-        int cnt = 0;
-        if (x < n - 1) {
-            cnt += p[1] != 0;
-            if (y < n - 1) cnt += p[stride + 1] != 0;
-            if (x < n - 2) cnt += p[2] != 0;
-        }
-        if (y < n - 1) {
-            if (((x & 3) || (y & 3)) && (((x + 1) & 3) || ((y + 2) & 3))) cnt += p[stride] != 0;
-            if (y < n - 2 && cnt < 4) cnt += p[2 * stride] != 0;
-        }
+        const uint32_t r0 = row[y] >> x, r1 = row[y + 1] >> x, r2 = row[y + 2] >> x;
+        int cnt = (int)((r0 >> 1) & 1u) + (int)((r1 >> 1) & 1u) + (int)((r0 >> 2) & 1u);
+        if (((x & 3) || (y & 3)) && (((x + 1) & 3) || ((y + 2) & 3))) cnt += (int)(r1 & 1u);
+        if (cnt < 4) cnt += (int)(r2 & 1u);
         cnt = (cnt + 1) >> 1;
         return ((luma && (x >> 2) + (y >> 2) > 0) ? 4 : 1) + off + cnt;
     }
@@ -633,6 +665,7 @@ extern "C" int x265amd_intra_write_picture(const x265amd_intra_syntax *s, uint8_
 
     Cabac cabac(o, s->qp);
     ResidualCoder res(cabac);
+    BlockMap map_y, map_u, map_v;
     for (int cy = 0; cy < ncy; cy++)
         for (int cx = 0; cx < ncx; cx++) {
             const int idx = cy * ncx + cx, my = s->mode_y[idx], mc = s->mode_c[idx];
@@ -662,13 +695,10 @@ extern "C" int x265amd_intra_write_picture(const x265amd_intra_syntax *s, uint8_
             const int16_t *by = s->level_y + (size_t)(cy * cu) * s->stride_y + cx * cu;
             const int16_t *bc[2] = {s->level_u + (size_t)(cy * half) * s->stride_c + cx * half,
                                     s->level_v + (size_t)(cy * half) * s->stride_c + cx * half};
-            auto any = [](const int16_t *b, int stride, int n) {
-                for (int y = 0; y < n; y++)
-                    for (int x = 0; x < n; x++)
-                        if (b[y * stride + x]) return 1u;
-                return 0u;
-            };
-            const uint32_t cbf_y = any(by, s->stride_y, cu), cbf_u = any(bc[0], s->stride_c, half), cbf_v = any(bc[1], s->stride_c, half);
+            map_y.scan(by, s->stride_y, cu);
+            map_u.scan(bc[0], s->stride_c, half);
+            map_v.scan(bc[1], s->stride_c, half);
+            const uint32_t cbf_y = map_y.any, cbf_u = map_u.any, cbf_v = map_v.any;
 
             // xWriteCU (src/encode.cpp:474-580)
             cabac.bin(1, kPartSize);  // 2Nx2N
@@ -696,9 +726,9 @@ extern "C" int x265amd_intra_write_picture(const x265amd_intra_syntax *s, uint8_
             cabac.bin(cbf_u, kCbfChroma);
             cabac.bin(cbf_v, kCbfChroma);
             cabac.bin(cbf_y, kCbfLuma);
-            if (cbf_y) res.code(by, s->stride_y, cu, true);
-            if (cbf_u) res.code(bc[0], s->stride_c, half, false);
-            if (cbf_v) res.code(bc[1], s->stride_c, half, false);
+            if (cbf_y) res.code(by, s->stride_y, cu, true, map_y);
+            if (cbf_u) res.code(bc[0], s->stride_c, half, false, map_u);
+            if (cbf_v) res.code(bc[1], s->stride_c, half, false, map_v);
             cabac.terminate(cy == ncy - 1 && cx == ncx - 1);
         }
     cabac.finish();
