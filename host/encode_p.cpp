@@ -1,10 +1,11 @@
 // encode_p -- closed-loop P-picture path of one GOP segment from a C++ host, through the C-ABI only.
 //
-//   x265amd_encode_p <in.yuv> <width> <height> <nframes> <qp> <range> <out_prefix>
+//   x265amd_encode_p <in.yuv> <width> <height> <nframes> <qp> <range> <out_prefix> [intra_cu]
 //
 // in.yuv: 8-bit 4:2:0 frames, Y,U,V each (the reference's input format, src/encode.cpp:1002-1003); width and
-// height multiples of 64.  Frame 0 opens the segment; its reconstruction is taken to be the source (intra
-// coding is outside the path).  Every following frame is searched against and predicted from the
+// height multiples of 64.  Frame 0 opens the segment: with intra_cu (16 or 32) it is coded as the reference codes
+// every picture -- GopEncoder::encode_i, the library's intra path -- and written to <out_prefix>.i.rec / .i.lvl /
+// .i.modes; without it its reconstruction is taken to be the source.  Every following frame is searched against and predicted from the
 // reconstruction before it.  Writes <out_prefix>.mv (x265amd_mv per CTU), .lvl (Int16 levels, Y,U,V),
 // .rec (reconstruction) -- frame after frame -- and prints one line per picture.
 //
@@ -125,13 +126,14 @@ int main(int argc, char **argv)
             return 1;
         }
     }
-    if (argc != 8) {
-        fprintf(stderr, "usage: %s <in.yuv> <width> <height> <nframes> <qp> <range> <out_prefix>\n", argv[0]);
+    if (argc != 8 && argc != 9) {
+        fprintf(stderr, "usage: %s <in.yuv> <width> <height> <nframes> <qp> <range> <out_prefix> [intra_cu]\n", argv[0]);
         return 2;
     }
     try {
         const int w = atoi(argv[2]), h = atoi(argv[3]), nframes = atoi(argv[4]), qp = atoi(argv[5]), range = atoi(argv[6]);
         const std::string prefix = argv[7];
+        const int icu = argc == 9 ? atoi(argv[8]) : 0;  // 16 / 32: the first picture goes through the intra path
         GopEncoder enc(w, h, 1, range, qp);
         const size_t fsz = enc.frame_bytes();
         std::vector<uint8_t> frame(fsz), rec(fsz);
@@ -141,6 +143,18 @@ int main(int argc, char **argv)
         File in(argv[1], "rb"), fmv(prefix + ".mv", "wb"), flvl(prefix + ".lvl", "wb"), frec(prefix + ".rec", "wb");
         for (int t = 0; t < nframes; t++) {
             if (fread(frame.data(), 1, fsz, in.f) != fsz) throw std::runtime_error("short read at frame " + std::to_string(t));
+            if (t == 0 && icu) {  // the I picture: <prefix>.i.rec / .i.lvl / .i.modes (luma modes, then chroma modes)
+                enc.encode_i(frame.data(), icu);
+                enc.fetch(nullptr, level.data(), rec.data());
+                std::vector<uint8_t> modes(2 * (size_t)(w / icu) * (h / icu));
+                enc.fetch_modes(modes.data(), modes.data() + modes.size() / 2);
+                File irec(prefix + ".i.rec", "wb"), ilvl(prefix + ".i.lvl", "wb"), imod(prefix + ".i.modes", "wb");
+                fwrite(rec.data(), 1, rec.size(), irec.f);
+                fwrite(level.data(), 2, level.size(), ilvl.f);
+                fwrite(modes.data(), 1, modes.size(), imod.f);
+                printf("POC %d: intra, CU %d, recon fnv1a %016llx\n", enc.poc(), icu, (unsigned long long)fnv1a(rec.data(), fsz));
+                continue;
+            }
             if (t == 0) {
                 enc.set_reference(frame.data());
                 continue;

@@ -106,6 +106,39 @@ class GopEncoder {
         rotate();
     }
 
+    // The I picture of every segment through the library's intra path (x265amd_intra_encode_frames: the segments
+    // are its batch of independent frames), CU = PU = TU = cu (16 or 32).  Levels land where encode_p leaves them;
+    // the reconstruction becomes refn[0].  Asynchronous; fetch() waits.  fetch_modes() brings the modes back.
+    void encode_i(const uint8_t *yuv, int cu = 32)
+    {
+        if ((cu != 16 && cu != 32)) throw Error(X265AMD_ERR_ARG, "GopEncoder::encode_i: CU 16 or 32");
+        const size_t ncu = (size_t)(w_ / cu) * (h_ / cu);
+        if (!pred_) pred_.reset(new DeviceBuffer(fsz_ * nseg_));
+        if (!mode_ || mode_->bytes() < 2 * ncu * nseg_) mode_.reset(new DeviceBuffer(2 * ncu * nseg_));
+        icu_ = cu;
+        check(x265amd_memcpy_h2d(cur_->as(), yuv, fsz_ * nseg_, stream_), "x265amd_memcpy_h2d");
+        poc_++;
+        x265amd_intra_frame f{};
+        f.width = w_, f.height = h_, f.cu = cu, f.qp = qp_, f.stride_y = w_, f.stride_c = w_ / 2;
+        uint8_t *rec = refn_[kMaxRefNum]->as();
+        f.d_src_y = cur_->as(), f.d_src_u = cur_->as(ysz_), f.d_src_v = cur_->as(ysz_ + csz_);
+        f.d_rec_y = rec, f.d_rec_u = rec + ysz_, f.d_rec_v = rec + ysz_ + csz_;
+        f.d_pred_y = pred_->as(), f.d_pred_u = pred_->as(ysz_), f.d_pred_v = pred_->as(ysz_ + csz_);
+        f.d_level_y = level_->as<int16_t>(), f.d_level_u = level_->as<int16_t>(2 * ysz_), f.d_level_v = level_->as<int16_t>(2 * (ysz_ + csz_));
+        f.d_mode_y = mode_->as(), f.d_mode_c = mode_->as(ncu * nseg_);
+        check(x265amd_intra_encode_frames(&f, nseg_, (int64_t)fsz_, (int64_t)fsz_, (int64_t)ncu, stream_), "x265amd_intra_encode_frames");
+        rotate();
+    }
+    // luma / chroma mode per CU of the last encode_i, [nseg][ncu] each (after sync())
+    void fetch_modes(uint8_t *mode_y, uint8_t *mode_c)
+    {
+        if (!mode_ || !icu_) throw Error(X265AMD_ERR_ARG, "GopEncoder::fetch_modes: no encode_i yet");
+        const size_t ncu = (size_t)(w_ / icu_) * (h_ / icu_);
+        check(x265amd_memcpy_d2h(mode_y, mode_->as(), ncu * nseg_, stream_), "x265amd_memcpy_d2h");
+        check(x265amd_memcpy_d2h(mode_c, mode_->as(ncu * nseg_), ncu * nseg_, stream_), "x265amd_memcpy_d2h");
+        sync();
+    }
+
     // One P picture per segment: yuv = nseg frames, Y,U,V each.  Asynchronous; fetch() waits.
     void encode_p(const uint8_t *yuv)
     {
@@ -194,11 +227,13 @@ class GopEncoder {
     size_t ysz_ = 0, csz_ = 0, fsz_ = 0, nctu_ = 0, ntu_ = 0, ws_bytes_ = 0;
     std::vector<std::unique_ptr<DeviceBuffer>> refn_;
     std::unique_ptr<DeviceBuffer> cur_, level_, mv_, cbf_, ws_;
+    std::unique_ptr<DeviceBuffer> pred_, mode_;  // encode_i's prediction planes and per-CU modes, made on first use
+    int icu_ = 0;
 };
 
 // Intra pictures: the pixel path of xEncEncode's CU loop (src/encode.cpp:668-941) on the GPU, frame by frame --
 // neighbour samples, luma and chroma mode decisions, prediction, transform stage, reconstruction.  What comes back
-// is what Stage 4 (xWriteCU, the entropy coder: host code, not part of this path) consumes: per CU the luma mode,
+// is what Stage 4 (xWriteCU, the entropy coder: host code, write_picture() below) consumes: per CU the luma mode,
 // the chroma mode, the coded-block sums, and the quantised levels; plus the reconstruction, over which the
 // reference takes its MD5 SEI (src/encode.cpp:945-950).
 class IntraEncoder {

@@ -150,3 +150,29 @@ def test_cpp_host_intra_encoder_reconstruction_md5(gpu, oracle, tmp_path):
     # geometry the reference rejects (src/params.cpp:73-77) comes back as an error, not a crash
     r = subprocess.run([exe, str(src), "100", "64", "1", "16", "30", prefix], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3 and "IntraEncoder" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_host_gop_with_intra_first_picture(gpu, oracle, tmp_path):
+    """x265amd_encode_p ... <intra_cu>: the segment's first picture goes through GopEncoder::encode_i (the library's
+    intra path); its reconstruction, levels and modes equal the oracle's intra frame, and the first P picture is
+    searched against and predicted from that reconstruction."""
+    from x265_amd import synth, MV_DTYPE
+    W, H, R, QP, T, CU = 256, 128, 16, 31, 2, 16
+    y, u, v = synth.make_sequence(W, H, T, search_range=R, seed=23, chroma=True)
+    yuv = np.concatenate([y.reshape(T, -1), u.reshape(T, -1), v.reshape(T, -1)], axis=1)
+    ysz = W * H
+    src = tmp_path / "in.yuv"
+    yuv.tofile(src)
+    prefix = str(tmp_path / "out")
+    r = subprocess.run([EXE, str(src), str(W), str(H), str(T), str(QP), str(R), prefix, str(CU)], capture_output=True, text=True,
+                       timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "intra, CU 16" in r.stdout
+    orec, my, mc, lv = oracle.intra_encode_frame(yuv[0], W, H, CU, QP, want_levels=True)
+    np.testing.assert_array_equal(np.fromfile(prefix + ".i.rec", np.uint8), orec)
+    np.testing.assert_array_equal(np.fromfile(prefix + ".i.lvl", np.int16), lv)
+    np.testing.assert_array_equal(np.fromfile(prefix + ".i.modes", np.uint8), np.concatenate([my, mc]))
+    gmv = np.fromfile(prefix + ".mv", MV_DTYPE)
+    omv = oracle.me_fullsearch(yuv[1][:ysz].reshape(H, W), orec[:ysz].reshape(H, W), 64, R, nthreads=8)
+    np.testing.assert_array_equal(gmv, omv.ravel())

@@ -782,3 +782,50 @@ def test_intra_frames_batch_equals_single_frames(gpu, oracle, w, h, cu, qp, n):
             orec, my, mc, lv = oracle.intra_encode_frame(yuv[fr], w, h, cu, qp, want_levels=True)
             np.testing.assert_array_equal(host(o["rec"][fr]), orec)
             np.testing.assert_array_equal(host(o["level"][fr]), lv)
+
+
+def test_closed_loop_gop_with_intra_first_picture(gpu, oracle):
+    """A whole GOP segment on the GPU: the I picture through the intra path (ClosedLoopGop.encode_i, the two segments
+    as its batch), the P pictures searched against and predicted from ITS reconstruction.  CPU chain: the oracle's
+    intra frame, then its search + TQ picture by picture."""
+    import hashlib
+    from x265_amd import synth, ClosedLoopGop
+    W, H, R, QP, T, CU = 256, 128, 16, 30, 3, 32
+    segs = []
+    for seed in (15, 16):
+        y, u, v = synth.make_sequence(W, H, T, search_range=R, seed=seed, chroma=True)
+        segs.append(np.concatenate([y.reshape(T, -1), u.reshape(T, -1), v.reshape(T, -1)], axis=1))
+    yuv = np.stack(segs)
+    S, ysz, csz = 2, W * H, (W // 2) * (H // 2)
+    enc = ClosedLoopGop(W, H, S, search_range=R, qp=QP)
+    rec0 = host(enc.encode_i(dev(yuv[:, 0]), cu=CU))
+    ref_cpu = []
+    for s in range(S):
+        orec, my, mc, lv = oracle.intra_encode_frame(yuv[s, 0], W, H, CU, QP, want_levels=True)
+        np.testing.assert_array_equal(rec0[s], orec)
+        np.testing.assert_array_equal(host(enc.level)[s], lv)
+        np.testing.assert_array_equal(host(enc.mode_y)[s], my)
+        np.testing.assert_array_equal(host(enc.mode_c)[s], mc)
+        ref_cpu.append(orec.copy())
+    qpc = oracle.chroma_qp(QP)
+    for t in range(1, T):
+        rec_gpu = host(enc.encode_p(dev(yuv[:, t])))
+        gmv = gpu.mv_to_numpy(enc.mv)[:, 0]
+        for s in range(S):
+            cur, ref = yuv[s, t], ref_cpu[s]
+            cy, ry = cur[:ysz].reshape(H, W), ref[:ysz].reshape(H, W)
+            omv = oracle.me_fullsearch(cy, ry, 64, R, nthreads=8)
+            np.testing.assert_array_equal(gmv[s], omv)
+            ly, _ = oracle.tq_forward(cy, ry, 32, QP, 1, mv=omv, mv_ctu=64)
+            rec = [oracle.tq_inverse(ly, ry, 32, QP, 1, mv=omv, mv_ctu=64).reshape(-1)]
+            cmv = omv.copy()
+            cmv["mvx"] >>= 1
+            cmv["mvy"] >>= 1
+            for k in range(2):
+                a, b = ysz + k * csz, ysz + (k + 1) * csz
+                cc, rc = cur[a:b].reshape(H // 2, W // 2), ref[a:b].reshape(H // 2, W // 2)
+                lc, _ = oracle.tq_forward(cc, rc, 16, qpc, 1, mv=cmv, mv_ctu=32)
+                rec.append(oracle.tq_inverse(lc, rc, 16, qpc, 1, mv=cmv, mv_ctu=32).reshape(-1))
+            ref_cpu[s] = np.concatenate(rec)
+            assert hashlib.md5(rec_gpu[s].tobytes()).hexdigest() == hashlib.md5(ref_cpu[s].tobytes()).hexdigest(), (s, t)
+    assert enc.poc == T - 1

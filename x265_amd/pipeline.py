@@ -92,8 +92,9 @@ class ClosedLoopGop:
     Pictures are the reference's frame layout (src/encode.cpp:41-45): one W*H*3/2 block, Y then U then V,
     stride = width.  Luma: 64x64 CTU search, 32x32 TUs.  Chroma (4:2:0): the luma vector >> 1
     (integer-pel; the build's own definition -- the reference has no inter prediction), 32x32 blocks,
-    16x16 TUs at g_aucChromaScale[qp] (src/encode.cpp:596).  The I picture that opens a segment is the
-    host's business (intra prediction is outside the path): hand its reconstruction to set_reference().
+    16x16 TUs at g_aucChromaScale[qp] (src/encode.cpp:596).  The I picture that opens a segment goes through
+    the intra path of the library (encode_i: x265amd_intra_encode_frames, the segments being its batch of
+    independent frames); a caller that makes it elsewhere hands its reconstruction to set_reference().
     """
     MAX_REF_NUM = 1  # inc/config.h
 
@@ -115,6 +116,28 @@ class ClosedLoopGop:
         self.workspace = torch.empty(max(api.me_workspace_bytes(width, height, search_range, nseg, 1), 16),
                                      dtype=torch.uint8, device=dev)
         self.poc = -1  # h->iPoc, src/encode.cpp:624
+        self.intra = None  # encode_i's buffers, made on first use
+
+    def encode_i(self, src_yuv, cu=32):
+        """The I picture of every segment (the reference's own picture type: src/encode.cpp:668-941), CU = PU = TU =
+        `cu`.  src_yuv: uint8 [S][W*H*3/2] on the GPU.  Leaves the levels in .level, the modes in .mode_y / .mode_c
+        ([S][ncus]), the reconstruction in refn[0]."""
+        if src_yuv.shape != (self.nseg, self.fsz) or src_yuv.dtype != torch.uint8 or not src_yuv.is_cuda:
+            raise TypeError("src_yuv: uint8 CUDA tensor [nseg][W*H*3/2]")
+        ncus = (self.h // cu) * (self.w // cu)
+        if self.intra is None or self.intra["mode_y"].shape[1] != ncus:
+            dev = src_yuv.device
+            zi = lambda: torch.zeros((self.nseg, ncus), dtype=torch.int32, device=dev)
+            self.intra = {"pred": torch.zeros((self.nseg, self.fsz), dtype=torch.uint8, device=dev),
+                          "mode_y": torch.zeros((self.nseg, ncus), dtype=torch.uint8, device=dev),
+                          "mode_c": torch.zeros((self.nseg, ncus), dtype=torch.uint8, device=dev),
+                          "cost_y": zi(), "cost_c": zi(), "abs_sum_y": zi(), "abs_sum_u": zi(), "abs_sum_v": zi()}
+        self.poc += 1
+        out = dict(self.intra, rec=self.refn[self.MAX_REF_NUM], level=self.level)
+        api.intra_encode_frames(src_yuv, self.w, self.h, cu, self.qp, out=out)
+        self.mode_y, self.mode_c = self.intra["mode_y"], self.intra["mode_c"]
+        self._rotate()
+        return self.refn[0]
 
     def planes(self, buf):
         """[S][W*H*3/2] picture (or level) buffer -> (Y [S][H][W], U, V [S][H/2][W/2]) views."""
