@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ME+TQ throughput of the MI355X hot path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p|4k|8k4ref|tq1080p|gop1080p]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 1080p|4k|8k4ref|tq1080p|gop1080p|intra1080p]
 
 One STEP = one pass of the hot path over one batch of synthetic frames that is
 already resident in HBM: exhaustive +-R integer-pel search for every 64x64 CTU
@@ -53,6 +53,7 @@ WORKLOADS = {
     "8k4ref": (7680, 4320, 64, 64, 4, 2, 32, 32),     # configs[4]
     "tq1080p": (1920, 1080, 64, 0, 1, 16, 32, 32),    # configs[2]: transform/quant only (see --tu), no search
     "gop1080p": (1920, 1080, 64, 64, 1, 16, 32, 32),  # closed-loop P pictures, 16 GOP segments, 4:2:0
+    "intra1080p": (1920, 1080, 32, 0, 0, 16, 32, 32),  # the reference's own picture type, CU 32, 16 frames per step
 }
 
 
@@ -468,6 +469,66 @@ def closed_loop(args, grp, nw, nh, rng, nseg, qp):
     grp.close()
 
 
+def intra_frames(args, grp, nw, nh, cu, fps, qp):
+    """The pixel path of the reference's intra encoder (x265amd_intra_encode_frames): `fps` independent frames per
+    step share every anti-diagonal step.  4:2:0; pixels counted: luma of the nominal picture, like the main metric."""
+    world, rank = grp.world, grp.rank
+    w, h = nw, (nh + cu - 1) // cu * cu
+    fsz = w * h * 3 // 2
+    T = 8
+    probe = synth.make_intra_probe(w, h, T)              # ONE sequence; this rank's frames = its shard of it
+    idx = [(rank * fps + k) % T for k in range(fps)]
+    yuv = torch.from_numpy(np.ascontiguousarray(probe[idx])).cuda()
+    out = x265_amd.intra_encode_frames(yuv, w, h, cu, qp)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def step(_k=None):
+        x265_amd.intra_encode_frames(yuv, w, h, cu, qp, out=out)
+
+    elapsed = timed(grp, args, step)
+    ev[0].record()
+    for _ in range(5):
+        step()
+    ev[1].record()
+    torch.cuda.synchronize()
+    dev_ms = ev[0].elapsed_time(ev[1]) / 5
+    cpu = None
+    if rank == 0 and not args.lean:
+        from oracle import pyoracle
+        orc = pyoracle.Oracle()
+        t0 = time.perf_counter()
+        orec, my, mc, lv = orc.intra_encode_frame(probe[idx[0]], w, h, cu, qp, want_levels=True)
+        dt = time.perf_counter() - t0
+        same = (np.array_equal(out["rec"][0].cpu().numpy(), orec) and np.array_equal(out["level"][0].cpu().numpy(), lv) and
+                np.array_equal(out["mode_y"][0].cpu().numpy(), my) and np.array_equal(out["mode_c"][0].cpu().numpy(), mc))
+        if not same:
+            raise SystemExit("intra1080p: GPU frame 0 differs from the oracle's restatement")
+        cpu = {"value": round(nw * nh / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+               "sample": f"one {w}x{h} frame through orc_intra_encode_frame ({dt * 1e3:.0f} ms); it is also the in-run parity "
+                         "check of the GPU's frame 0 (reconstruction, levels, modes: identical)"}
+    if rank == 0:
+        nsteps = w // cu + 2 * (h // cu - 1)
+        alg = fps * fsz * (1 + 1 + 2)   # source in, reconstruction out, Int16 levels out (4:2:0: 1.5 samples per pixel)
+        print(json.dumps({
+            "metric": "intra pixel-path Mpixels/s", "value": round(nw * nh * fps * world * args.steps / elapsed / 1e6, 2),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{nw}x{nh} 4:2:0 (padded {w}x{h}) intra pictures, CU = PU = TU = {cu}, QP{qp}, SLICE_I: "
+                                   f"{fps} independent frames per step per GPU through x265amd_intra_encode_frames "
+                                   f"({nsteps} anti-diagonal steps of 3 launches: prediction + decisions, luma TQ, chroma TQ)",
+                       "name": args.workload, "frames_per_step_per_gpu": fps},
+            "roofline": {"kernel": "the whole step (intra_wave_kernel + tq_mfma_kernel x 2 per anti-diagonal)", "bound": "hbm",
+                         "achieved": round(alg / (dev_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "algorithmic bytes = source + reconstruction + Int16 levels; the step is a chain of "
+                                 f"{3 * nsteps} dependent launches of at most {fps} x {min(h // cu, (w // cu + 1) // 2)} workgroups, "
+                                 "bound by that chain's latency, not by HBM or the VALU (DESIGN.md 4.6)"},
+            "cpu_baseline": cpu,
+        }), flush=True)
+    grp.close()
+
+
 def pmc_traffic(key, field):
     """HBM-side bytes per launch from the PMC passes committed under profiles/ (tools/run_pmc.sh; separate
     --pmc runs, gfx950 corrections): counters cannot be collected inside this run."""
@@ -614,6 +675,8 @@ def main():
         return tq_only(args, grp, nw, nh, ctu, fps, tu, qp)
     if args.workload == "gop1080p":
         return closed_loop(args, grp, nw, nh, rng, fps, qp)
+    if args.workload == "intra1080p":
+        return intra_frames(args, grp, nw, nh, ctu, fps, qp)
     return search_and_tq(args, grp, nw, nh, ctu, rng, nrefs, fps, tu, qp)
 
 

@@ -49,7 +49,7 @@ def main():
         with open(os.path.join(DST, f"{rnd}_pmc_sq.json"), "w") as o:
             json.dump(sq, o, indent=1, sort_keys=True)
         n += 1
-    for name in ("pu_bench", "intra_bench", "tq_trace"):
+    for name in ("pu_bench", "intra_bench", "tq_trace", "encode_i_bench"):
         p = os.path.join(SRC, name + ".txt")
         if os.path.exists(p):
             with open(p) as i, open(os.path.join(DST, f"{rnd}_{name}.txt"), "w") as o:

@@ -18,13 +18,15 @@ bench)
     timeout -k 10 200 python bench.py --workload tq1080p --tu $TU --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_tq1080p_tu$TU.json 2> $OUT/bench_tq_tu$TU.err
   done
   echo "tq done"
+  timeout -k 10 300 python bench.py --workload intra1080p > $OUT/bench_intra1080p.json 2> $OUT/bench_intra1080p.err; echo "intra1080p done"
   timeout -k 10 200 python tools/pu_bench.py > $OUT/pu_bench.txt 2>&1; echo "pu done"
   timeout -k 10 300 python tools/intra_bench.py > $OUT/intra_bench.txt 2>&1; echo "intra done"
   timeout -k 10 100 python tools/tq_trace.py 32 16 > $OUT/tq_trace.txt 2>&1; echo "tq trace done"
+  timeout -k 10 400 bash tools/encode_i_bench.sh > $OUT/encode_i_bench.txt 2>&1; echo "encode_i done"
   ;;
 trace)
   cd /tmp && export TMPDIR=/tmp
-  for WL in 1080p 4k 8k4ref gop1080p tq1080p; do
+  for WL in 1080p 4k 8k4ref gop1080p tq1080p intra1080p; do
     timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $OUT/trace_$WL --output-format csv -- python3 $ROOT/bench.py --workload $WL --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace_$WL.log 2>&1
     echo "trace $WL done"
   done
