@@ -28,6 +28,14 @@ __device__ const int8_t kIntraAngle[35] = {0,   0,   32,  26,  21,  17,  13,  9,
 __device__ const int16_t kIntraInvAngle[35] = {0,   0,   256, 315, 390, 482, 630, 910, 1638, 4096, 0,   4096, 1638, 910, 630, 482, 390, 315,
                                                256, 315, 390, 482, 630, 910, 1638, 4096, 0,  4096, 1638, 910, 630, 482, 390, 315, 256};
 
+// |a - b| + acc in one instruction (v_sad_u32)
+__device__ __forceinline__ uint32_t sad_acc(uint32_t a, uint32_t b, uint32_t acc)
+{
+    uint32_t d;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(acc));
+    return d;
+}
+
 constexpr int kMaxRef = 4 * 32 + 1;
 constexpr int kMainRow = 3 * 32 + 8;  // refMain of a mode: samples -N .. 2N, and one past the end that a zero weight may touch
 
@@ -103,8 +111,7 @@ template <int N, bool LUMA> __device__ __forceinline__ int intra_ang_pixel(const
     const int pos = (k + 1) * ang;
     const int idx = pos >> 5, fact = pos & 31;
     const uint8_t *m = row + N + x + idx + 1;
-    int p = m[0];
-    if (fact) p = ((32 - fact) * p + fact * m[1] + 16) >> 5;
+    int p = ((32 - fact) * m[0] + fact * m[1] + 16) >> 5;  // fact == 0: (32 m[0] + 16) >> 5 = m[0]; m[1] is a valid entry (kMainRow)
     if (LUMA && ang == 0 && x == 0) {
         const uint8_t *tl = ref + 2 * N;
         p += (tl[(hor ? 1 : -1) * (k + 1)] - tl[0]) >> 1;
@@ -139,13 +146,13 @@ __device__ __forceinline__ void intra_luma_sads(const uint8_t (*s_ref)[kMaxRef +
 #pragma unroll
             for (int t = 0; t < PER; t++) {
                 const int i = lane + 64 * t;
-                if (i < N * N) s += (uint32_t)abs(sp[t] - intra_ang_pixel<N, true>(ref, main_row, mode, i >> L2, i & (N - 1)));
+                if (i < N * N) s = sad_acc((uint32_t)sp[t], (uint32_t)intra_ang_pixel<N, true>(ref, main_row, mode, i >> L2, i & (N - 1)), s);
             }
         } else {
 #pragma unroll
             for (int t = 0; t < PER; t++) {
                 const int i = lane + 64 * t;
-                if (i < N * N) s += (uint32_t)abs(sp[t] - intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc));
+                if (i < N * N) s = sad_acc((uint32_t)sp[t], (uint32_t)intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc), s);
             }
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
