@@ -308,6 +308,24 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
     const int x0 = cux * N, y0 = cuy * N, cu = cuy * w.ncx + cux;
     const bool bL = cux > 0, bT = cuy > 0, bTR = bT && cux + 1 < w.ncx;
 
+    // the lane's source pixels and the left neighbour's mode: asked for first, so that they travel together with the
+    // reference samples (one memory latency instead of two)
+    int sp[PER];
+#pragma unroll
+    for (int t = 0; t < PER; t++) {
+        const int i = lane + 64 * t;
+        sp[t] = f.d_src_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))];
+    }
+    int su[PERC], sv[PERC];
+#pragma unroll
+    for (int t = 0; t < PERC; t++) {
+        const int i = lane + 64 * t;
+        const int64_t o = (int64_t)(y0 / 2 + (i >> L2C)) * f.stride_c + x0 / 2 + (i & (NC - 1));
+        su[t] = f.d_src_u[o];
+        sv[t] = f.d_src_v[o];
+    }
+    const int left_mode = (tid == NT - 1 && bL) ? f.d_mode_y[cu - 1] : 1;
+
     // ---- reference samples: luma, and its smoothed copy; U and V ----
     if (tid <= 4 * N) s_ref[0][tid] = (uint8_t)intra_ref_sample(f.d_rec_y, f.stride_y, x0, y0, N, tid, bL, bT, bTR);
     for (int i = tid; i < 2 * (4 * NC + 1); i += NT) {
@@ -325,7 +343,7 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
     if (tid == NT - 1) {
         // most probable modes (:1268-1293).  The mode above counts only inside the same CU there (`bT && uiY`
         // with uiY the offset inside the CU, always 0): it is DC whatever the CU above chose.
-        const int left = bL ? f.d_mode_y[cu - 1] : 1, top = 1;
+        const int left = left_mode, top = 1;
         int m0, m1, m2;
         if (left == top) {
             if (left > 1)
@@ -337,20 +355,6 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
             m2 = (left != 0 && top != 0) ? 0 : (left + top) < 2 ? 26 : 1;
         }
         s_mpm[0] = m0, s_mpm[1] = m1, s_mpm[2] = m2;
-    }
-    int sp[PER];
-#pragma unroll
-    for (int t = 0; t < PER; t++) {
-        const int i = lane + 64 * t;
-        sp[t] = f.d_src_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))];
-    }
-    int su[PERC], sv[PERC];
-#pragma unroll
-    for (int t = 0; t < PERC; t++) {
-        const int i = lane + 64 * t;
-        const int64_t o = (int64_t)(y0 / 2 + (i >> L2C)) * f.stride_c + x0 / 2 + (i & (NC - 1));
-        su[t] = f.d_src_u[o];
-        sv[t] = f.d_src_v[o];
     }
     __syncthreads();
 
