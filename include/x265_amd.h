@@ -151,8 +151,10 @@ int x265amd_me_fullsearch(const uint8_t *d_cur, const uint8_t *d_ref, int width,
  * the first strict minimum of src/encode.cpp:762-765 is untouched.  Needs a
  * caller-provided device workspace of x265amd_me_workspace_bytes() bytes
  * (16-byte aligned) for the reference box sums, the per-group bounds and the
- * first-batch schedule; ctu must be 64. */
-size_t x265amd_me_workspace_bytes(int width, int height, int range, int nframes, int nrefs);
+ * first-batch schedule.  ctu: 64, or 32 (a 32x32 PU grid; its bound is the sum over the sixteen 8x8 sub-blocks:
+ * the same kernels instantiated at half the size) -- then the workspace is x265amd_me_workspace_bytes_ctu(). */
+size_t x265amd_me_workspace_bytes(int width, int height, int range, int nframes, int nrefs); /* ctu = 64 */
+size_t x265amd_me_workspace_bytes_ctu(int width, int height, int ctu, int range, int nframes, int nrefs);
 int x265amd_me_fullsearch_sea(const uint8_t *d_cur, const uint8_t *d_ref, int width, int height,
                               int stride, int ctu, int range, int nframes,
                               int64_t cur_frame_stride, int64_t ref_frame_stride, int nrefs,

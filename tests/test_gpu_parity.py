@@ -178,7 +178,7 @@ def test_me_golden(gpu, method):
     z, meta = load_golden("me_small.npz")
     for m in meta:
         k = m["id"]
-        if method == "sea" and m["ctu"] != 64:
+        if method == "sea" and m["ctu"] not in (64, 32):
             continue
         got = gpu.mv_to_numpy(gpu.me_fullsearch(dev(z[f"me{k}_cur"]), dev(z[f"me{k}_ref"]), m["ctu"], m["range"],
                                                 method=method))
@@ -190,11 +190,12 @@ def test_me_golden(gpu, method):
 @pytest.mark.parametrize("method", ["brute", "sea"])
 @pytest.mark.parametrize("ctu,rng_,w,h", [(64, 64, 256, 192), (64, 33, 320, 128), (32, 24, 160, 96),
                                           (16, 16, 96, 64), (64, 128, 192, 192), (64, 1, 128, 64),
-                                          (64, 0, 128, 64)])
+                                          (64, 0, 128, 64), (32, 64, 256, 160), (32, 128, 192, 160), (32, 1, 96, 32),
+                                          (32, 0, 64, 64), (32, 37, 416, 96)])
 def test_me_vs_oracle(gpu, oracle, ctu, rng_, w, h, method):
     from x265_amd import synth
-    if method == "sea" and ctu != 64:
-        pytest.skip("successive elimination is built for the 64x64 CTU only")
+    if method == "sea" and ctu not in (64, 32):
+        pytest.skip("successive elimination is built for 64x64 and 32x32 blocks")
     seq = synth.make_sequence(w, h, 3, search_range=min(rng_, 48), seed=ctu * 1000 + rng_)
     cur = np.ascontiguousarray(seq[1:])
     ref = np.ascontiguousarray(seq[:-1])
@@ -296,9 +297,10 @@ def test_me_sea_equals_exhaustive_on_hostile_content(gpu):
     seq = synth.make_sequence(640, 384, 2, search_range=64, seed=5)
     cases.append((seq[1], seq[0], 64))
     for cur, ref, r in cases:
-        x = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), 64, r, method="brute"))
-        y = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), 64, r, method="sea"))
-        np.testing.assert_array_equal(x, y)
+        for ctu in (64, 32):
+            x = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, r, method="brute"))
+            y = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, r, method="sea"))
+            np.testing.assert_array_equal(x, y, f"ctu {ctu} range {r}")
 
 
 def test_me_argument_errors(gpu):
@@ -396,7 +398,9 @@ def test_me_sea_strides_batches_and_workspace(gpu, oracle):
     with pytest.raises(gpu.X265AmdError):
         gpu.me_fullsearch(frames[1:], frames[:-1], 64, R, method="sea", workspace=ws[4:])      # not 16-byte aligned
     with pytest.raises(gpu.X265AmdError):
-        gpu.me_fullsearch(frames[1:], frames[:-1], 32, R, method="sea", workspace=ws)          # SEA is CTU 64 only
+        gpu.me_fullsearch(frames[1:], frames[:-1], 16, R, method="sea", workspace=ws)          # SEA: blocks of 64 or 32
+    with pytest.raises(gpu.X265AmdError):
+        gpu.me_fullsearch(frames[1:], frames[:-1], 32, R, method="sea", workspace=ws)          # 32x32 blocks need a larger workspace
 
 
 def test_tq_mv_shift_chroma_vs_oracle(gpu, oracle):
@@ -558,6 +562,8 @@ def test_me_odd_and_degenerate_ranges_vs_oracle(gpu, oracle, R):
         np.testing.assert_array_equal(got, want, f"R {R} {method}")
     tree = gpu.me_fullsearch_pu(cur, ref, R)
     np.testing.assert_array_equal(gpu.mv_to_numpy(tree[64])[0, 0], want)
+    want32 = oracle.me_fullsearch(seq[1], seq[0], 32, R, nthreads=8)
+    np.testing.assert_array_equal(gpu.mv_to_numpy(gpu.me_fullsearch(cur, ref, 32, R, method="sea"))[0, 0], want32, f"R {R} sea 32")
     np.testing.assert_array_equal(gpu.mv_to_numpy(tree[16])[0, 0], oracle.me_fullsearch(seq[1], seq[0], 16, R, nthreads=8))
 
 
@@ -829,3 +835,22 @@ def test_closed_loop_gop_with_intra_first_picture(gpu, oracle):
             ref_cpu[s] = np.concatenate(rec)
             assert hashlib.md5(rec_gpu[s].tobytes()).hexdigest() == hashlib.md5(ref_cpu[s].tobytes()).hexdigest(), (s, t)
     assert enc.poc == T - 1
+
+
+def test_me_sea_32x32_blocks_1080p(gpu, oracle):
+    """The elimination search on a 32x32 PU grid (the same kernels at half the size, 8x8 sub-block bounds) at
+    BASELINE configs[1]'s geometry, two frames batched: every vector and cost equals the every-candidate kernel's,
+    a sample of blocks equals the oracle's, and the workspace can be reused."""
+    from x265_amd import synth, api
+    W, H, R = 1920, 1088, 64
+    seq = synth.make_sequence(W, H, 3, search_range=R, seed=12345)
+    cur, ref = dev(np.ascontiguousarray(seq[1:])), dev(np.ascontiguousarray(seq[:-1]))
+    ws = torch.empty(api.me_workspace_bytes(W, H, R, 2, 1, 32), dtype=torch.uint8, device="cuda")
+    a = gpu.mv_to_numpy(gpu.me_fullsearch(cur, ref, 32, R, method="brute"))
+    for _ in range(2):
+        b = gpu.mv_to_numpy(gpu.me_fullsearch(cur, ref, 32, R, method="sea", workspace=ws))
+        np.testing.assert_array_equal(a, b)
+    for f in range(2):
+        want = oracle.me_fullsearch(seq[f + 1], seq[f], 32, R, first=5 + f, step=211, nthreads=8)   # every 211th block
+        idx = np.arange(5 + f, a.shape[2], 211)
+        np.testing.assert_array_equal(a[f, 0][idx], want[idx], f"frame {f}")

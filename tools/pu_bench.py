@@ -25,6 +25,10 @@ for ctu in (64, 32, 16):
     print("PU %2d  every candidate      %6.2f ms  %6.0f Mpix/s" % (ctu, dt * 1e3, 1920 * 1080 * NF / dt / 1e6))
 _, dt = timed(lambda: x265_amd.me_fullsearch(fr[1:], fr[:-1], 64, R, method="sea"))
 print("PU 64  successive elimination %6.2f ms  %6.0f Mpix/s" % (dt * 1e3, 1920 * 1080 * NF / dt / 1e6))
+ws32 = torch.empty(x265_amd.me_workspace_bytes(1920, 1088, R, NF, 1, 32), dtype=torch.uint8, device="cuda")
+sea32, dt = timed(lambda: x265_amd.me_fullsearch(fr[1:], fr[:-1], 32, R, method="sea", workspace=ws32))
+print("PU 32  successive elimination %6.2f ms  %6.0f Mpix/s   identical to every candidate: %s" %
+      (dt * 1e3, 1920 * 1080 * NF / dt / 1e6, torch.equal(sea32, res[32])))
 tree, dt = timed(lambda: x265_amd.me_fullsearch_pu(fr[1:], fr[:-1], R))
 print("PU 64 + 32 + 16, one pass     %6.2f ms  %6.0f Mpix/s" % (dt * 1e3, 1920 * 1080 * NF / dt / 1e6))
 t2, dt = timed(lambda: x265_amd.me_fullsearch_pu(fr[1:], fr[:-1], R, sizes=(32, 16)))

@@ -84,6 +84,7 @@ SIGNATURES = {
     "x265amd_intra_stream_bound": (C.c_size_t, [C.c_int, C.c_int]),
     "x265amd_intra_write_picture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "x265amd_me_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "x265amd_me_workspace_bytes_ctu": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "x265amd_me_fullsearch_sea": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -227,7 +228,9 @@ def satd_blocks(w, n, src, stride_src, ref, stride_ref, src_off, ref_off):
 # --------------------------------------------------------------------------
 # motion search
 # --------------------------------------------------------------------------
-def me_workspace_bytes(width, height, search_range, nframes, nrefs):
+def me_workspace_bytes(width, height, search_range, nframes, nrefs, ctu=64):
+    if ctu != 64:
+        return int(_lib().x265amd_me_workspace_bytes_ctu(width, height, ctu, search_range, nframes, nrefs))
     return int(_lib().x265amd_me_workspace_bytes(width, height, search_range, nframes, nrefs))
 
 
@@ -241,7 +244,7 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
     (mvx|mvy<<16, sad) -- use mv_to_numpy() for a structured host copy.
 
     method: "brute" = x265amd_me_fullsearch (every candidate's SAD), "sea" =
-    x265amd_me_fullsearch_sea (exact successive elimination, same result; CTU 64 only;
+    x265amd_me_fullsearch_sea (exact successive elimination, same result; CTU 64 or 32;
     `workspace` = uint8 CUDA tensor of me_workspace_bytes() or None to allocate one),
     "sea_static" = x265amd_me_fullsearch_sea_static (the same search on the library's static scratch: the
     call allocates nothing, `out` must be given; jobs beyond me_static_workspace_bytes() are refused),
@@ -273,7 +276,7 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
         return out
     use_sea = method == "sea" or (method == "auto" and ctu == 64 and w > 0 and h > 0 and w % 64 == 0 and h % 64 == 0)
     if use_sea:
-        need = me_workspace_bytes(w, h, search_range, f, nrefs)
+        need = me_workspace_bytes(w, h, search_range, f, nrefs, ctu)
         if workspace is None:
             workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=cur.device)
         _dev(workspace, torch.uint8, "workspace")

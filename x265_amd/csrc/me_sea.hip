@@ -37,14 +37,18 @@ namespace x265amd {
 // the rows -- into LDS; (3) pairs out, 8 bytes per lane.  HBM: 1.5 B/px read, 4 B/px written (two kernels
 // with H16 in memory moved 9.5 B/px).
 constexpr int kBoxTW = 112, kBoxTH = 64;   // tile of P
-constexpr int kBoxCols = kBoxTW + 16;      // B16 / H16 columns per tile: 64 pairs = one per thread and quarter
-constexpr int kBoxRows = kBoxTH + 15;      // H16 rows per tile
 constexpr int kBoxPitch = 136;             // u16 per LDS row: 272 B, a multiple of 8
+// S = side of the sub-blocks: 16 for the 64x64 search, 8 for the 32x32 search (a quarter of the block either way)
+template <int S>
 __global__ __launch_bounds__(256) void box16_pairs(const uint8_t *__restrict__ ref_base, uint32_t *__restrict__ pbuf,
                                                    int width, int height, int stride, int nrefs, int64_t ref_fs,
                                                    int64_t ref_rs, uint32_t *__restrict__ ctrl)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t Ht[kBoxRows][kBoxPitch];
+    constexpr int kBoxCols = kBoxTW + S;      // B / H columns per tile (S = 16: 64 pairs = one per thread and quarter)
+    constexpr int kBoxRows = kBoxTH + S - 1;  // H rows per tile
+    constexpr int ND = S / 4 + 1;             // dwords of pixels under four neighbouring S-sums
+    static_assert(kBoxCols % 4 == 0 && kBoxCols <= kBoxPitch && kBoxCols <= 128, "tile geometry");
+    __shared__ __attribute__((aligned(16))) uint16_t Ht[kBoxTH + 15][kBoxPitch];
     __shared__ __attribute__((aligned(16))) uint16_t Bt[kBoxTH][kBoxPitch];
     // the queue counters of the later kernels start from zero (stream order: this grid ends first)
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 8) ctrl[threadIdx.x] = 0;
@@ -53,53 +57,54 @@ __global__ __launch_bounds__(256) void box16_pairs(const uint8_t *__restrict__ r
     const int f = pl / nrefs, r_ = pl - f * nrefs;
     const uint8_t *ref = ref_base + f * ref_fs + r_ * ref_rs;
 
-    // (1) H16[r][c] = sum_{k<16} p[y0 + r][x0 + c + k]; pixels outside the picture count as 0 (sums that
+    // (1) H[r][c] = sum_{k<S} p[y0 + r][x0 + c + k]; pixels outside the picture count as 0 (sums that
     //     include them belong to sub-blocks no legal candidate uses)
     for (int i = tid; i < kBoxRows * (kBoxCols / 4); i += 256) {
         const int r = i / (kBoxCols / 4), gq = i - r * (kBoxCols / 4);
         const int y = y0 + r, x = x0 + 4 * gq;
-        uint32_t d[5];
+        uint32_t d[ND];
 #pragma unroll
-        for (int k = 0; k < 5; k++)
+        for (int k = 0; k < ND; k++)
             d[k] = (y < height && x + 4 * k + 4 <= width) ? *reinterpret_cast<const uint32_t *>(ref + (int64_t)y * stride + x + 4 * k) : 0u;
-        uint32_t s0 = __builtin_amdgcn_sad_u8(d[0], 0u, 0u);
-        s0 = __builtin_amdgcn_sad_u8(d[1], 0u, s0);
-        s0 = __builtin_amdgcn_sad_u8(d[2], 0u, s0);
-        s0 = __builtin_amdgcn_sad_u8(d[3], 0u, s0);
-        const uint32_t s1 = s0 - (d[0] & 255u) + (d[4] & 255u);
-        const uint32_t s2 = s1 - ((d[0] >> 8) & 255u) + ((d[4] >> 8) & 255u);
-        const uint32_t s3 = s2 - ((d[0] >> 16) & 255u) + ((d[4] >> 16) & 255u);
+        uint32_t s0 = 0;
+#pragma unroll
+        for (int k = 0; k < ND - 1; k++) s0 = __builtin_amdgcn_sad_u8(d[k], 0u, s0);
+        const uint32_t s1 = s0 - (d[0] & 255u) + (d[ND - 1] & 255u);
+        const uint32_t s2 = s1 - ((d[0] >> 8) & 255u) + ((d[ND - 1] >> 8) & 255u);
+        const uint32_t s3 = s2 - ((d[0] >> 16) & 255u) + ((d[ND - 1] >> 16) & 255u);
         *reinterpret_cast<uint2 *>(&Ht[r][4 * gq]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
     }
     __syncthreads();
 
-    // (2) B16[r][c] = sum_{j<16} H16[r + j][c]: packed u16 pairs; 16 * 4080 < 2^16, so the packed adds never
+    // (2) B[r][c] = sum_{j<S} H[r + j][c]: packed u16 pairs; S * S * 255 < 2^16, so the packed adds never
     //     carry across, and the old row is taken out before the new one goes in (no borrow either)
     {
         const int cp = tid & 63, q = tid >> 6;  // column pair, quarter of the tile's rows
         constexpr int pd = kBoxPitch / 2;       // LDS pitch in dwords
-        const uint32_t *h = reinterpret_cast<const uint32_t *>(&Ht[0][0]) + cp;
-        uint32_t *bt = reinterpret_cast<uint32_t *>(&Bt[0][0]) + cp;
-        const int rb = 16 * q;
-        uint32_t acc = 0;
+        if (2 * cp < kBoxCols) {
+            const uint32_t *h = reinterpret_cast<const uint32_t *>(&Ht[0][0]) + cp;
+            uint32_t *bt = reinterpret_cast<uint32_t *>(&Bt[0][0]) + cp;
+            const int rb = 16 * q;
+            uint32_t acc = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) acc += h[(rb + k) * pd];
-        bt[rb * pd] = acc;
+            for (int k = 0; k < S; k++) acc += h[(rb + k) * pd];
+            bt[rb * pd] = acc;
 #pragma unroll
-        for (int j = 1; j < 16; j++) {
-            acc = (acc - h[(rb + j - 1) * pd]) + h[(rb + j + 15) * pd];
-            bt[(rb + j) * pd] = acc;
+            for (int j = 1; j < 16; j++) {
+                acc = (acc - h[(rb + j - 1) * pd]) + h[(rb + j + S - 1) * pd];
+                bt[(rb + j) * pd] = acc;
+            }
         }
     }
     __syncthreads();
 
-    // (3) pairs out: P[y][x] = B16[y][x] | B16[y][x + 16] << 16, two columns (8 bytes) per item
+    // (3) pairs out: P[y][x] = B[y][x] | B[y][x + S] << 16, two columns (8 bytes) per item
     for (int i = tid; i < kBoxTH * (kBoxTW / 2); i += 256) {
         const int r = i / (kBoxTW / 2), c = i - r * (kBoxTW / 2);
         const int y = y0 + r, x = x0 + 2 * c;
-        if (y + 16 > height || x + 2 > width) continue;
+        if (y + S > height || x + 2 > width) continue;
         const uint32_t an = *reinterpret_cast<const uint32_t *>(&Bt[r][2 * c]);
-        const uint32_t af = *reinterpret_cast<const uint32_t *>(&Bt[r][2 * c + 16]);
+        const uint32_t af = *reinterpret_cast<const uint32_t *>(&Bt[r][2 * c + S]);
         *reinterpret_cast<uint2 *>(pbuf + ((int64_t)pl * height + y) * width + x) =
             make_uint2((an & 0xffffu) | (af << 16), (an >> 16) | (af & 0xffff0000u));
     }
@@ -111,18 +116,19 @@ struct SeaLayout {
     int ngroups;
 };
 
-__host__ __device__ inline SeaLayout sea_layout(int w, int h, int range, int cx, int cy)
+// B = side of the searched block (64 or 32)
+__host__ __device__ inline SeaLayout sea_layout(int w, int h, int range, int cx, int cy, int B = 64)
 {
     SeaLayout L;
     L.dylo = -range > -cy ? -range : -cy;
-    L.dyhi = range < h - 64 - cy ? range : h - 64 - cy;
+    L.dyhi = range < h - B - cy ? range : h - B - cy;
     L.dxlo = -range > -cx ? -range : -cx;
-    L.dxhi = range < w - 64 - cx ? range : w - 64 - cx;
+    L.dxhi = range < w - B - cx ? range : w - B - cx;
     L.wx0 = (cx + L.dxlo) & ~3;
     L.ngx = (cx + L.dxlo - L.wx0 + (L.dxhi - L.dxlo + 1) + 3) >> 2;
     L.ndy = L.dyhi - L.dylo + 1;
-    L.pitch = (L.ngx + 17) | 1;
-    L.win_rows = 64 + L.ndy;
+    L.pitch = (L.ngx + B / 4 + 1) | 1;
+    L.win_rows = B + L.ndy;
     L.ngroups = L.ngx * L.ndy;
     return L;
 }
@@ -137,9 +143,12 @@ __device__ __forceinline__ int lb_bin(uint32_t lb)
     return e < 0 ? 0 : e;
 }
 
-constexpr int kMaxChain = 20;     // chain steps of 16 rows: ndy <= 257 (R <= 128) needs 17
+// chain steps of S rows that a lane may walk (a multiple of 5, the rotation period of its band registers):
+// ndy <= 257 (R <= 128) needs 17 at S = 16 and 33 at S = 8
+__host__ __device__ constexpr int sea_max_chain(int S) { return S == 16 ? 20 : 35; }
 constexpr int kBoundsThreads = 512;  // 8 waves, 4 workgroups per CU
 constexpr uint32_t kIllegal = 1u << 30;  // > any bound (16 * 65280)
+// the search geometry of one launch: the kernels are instantiated for blocks of 64 (sub-blocks of 16) and of 32 (8)
 constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or already scheduled
 
 // Bounds are kept as u16 = floor(LB / 16) (LB <= 16 * 65280): still a lower bound, 15 units coarser.
@@ -161,6 +170,7 @@ __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est
 //   out: gl[plane][ctu][max_groups] u16 bound per group (kNone where scheduled / illegal),
 //        list0[plane][ctu][..] the first batch (the kFirst groups of the lowest histogram bins), hdr
 // ---------------------------------------------------------------------------------------------
+template <int B>
 __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
                                                                    const uint8_t *__restrict__ ref_base,
                                                                  const uint32_t *__restrict__ pbuf,
@@ -169,6 +179,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
                                                                  uint32_t *__restrict__ ctrl, const MeGeom g, int gl_pitch,
                                                                  int nplanes, uint32_t *__restrict__ stats)
 {
+    constexpr int S = B / 4;  // side of a sub-block
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint16_t *glb = reinterpret_cast<uint16_t *>(smem);  // [ndy][ngx]
     __shared__ uint32_t hist[kBins];
@@ -192,8 +203,8 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     const int plane = ctu_lin / (g.ctus_x * g.ctus_y), cin = ctu_lin - plane * (g.ctus_x * g.ctus_y);
     const int cty = cin / g.ctus_x, ctx = cin - cty * g.ctus_x;
     const int f = plane / g.nrefs;
-    const int cx = ctx * 64, cy = cty * 64;
-    const SeaLayout L = sea_layout(g.width, g.height, g.range, cx, cy);
+    const int cx = ctx * B, cy = cty * B;
+    const SeaLayout L = sea_layout(g.width, g.height, g.range, cx, cy, B);
     const uint8_t *cur = cur_base + f * g.cur_fs;
     const uint32_t *P = pbuf + (int64_t)plane * g.height * g.width;
     const int64_t ctu_id = ctu_lin;
@@ -207,16 +218,15 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         min_key = 0xffffffffu;
         rest_lb = kNone;
     }
-    // ---- the CTU's sub-block sums: 16 lanes per sub-block, one 16-pixel row each ----
-    if (tid < 256) {
-        const int b = tid >> 4, rrow = tid & 15;
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(cur + (int64_t)(cy + 16 * (b >> 2) + rrow) * g.stride + cx + 16 * (b & 3));
-        uint32_t s = __builtin_amdgcn_sad_u8(p[0], 0u, 0u);
-        s = __builtin_amdgcn_sad_u8(p[1], 0u, s);
-        s = __builtin_amdgcn_sad_u8(p[2], 0u, s);
-        s = __builtin_amdgcn_sad_u8(p[3], 0u, s);
+    // ---- the block's sub-block sums: S lanes per sub-block, one S-pixel row each ----
+    if (tid < 16 * S) {
+        const int b = tid / S, rrow = tid % S;
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(cur + (int64_t)(cy + S * (b >> 2) + rrow) * g.stride + cx + S * (b & 3));
+        uint32_t s = 0;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+        for (int k = 0; k < S / 4; k++) s = __builtin_amdgcn_sad_u8(p[k], 0u, s);
+#pragma unroll
+        for (int o = 1; o < S; o <<= 1) s += __shfl_xor(s, o);
         if (rrow == 0) csum[b] = s;
     }
     __syncthreads();
@@ -233,7 +243,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     const int ndx = L.dxhi - L.dxlo + 1;
     uint32_t my_min = 0xffffffffu;  // (stored bound << 16 | group) of the lane's best group
     {
-        const int nchain = 16 * L.ngx;  // (c, gx)
+        const int nchain = S * L.ngx;  // (c, gx)
         // whole sweeps of chains; a short remainder (the 33rd column of groups of a +-64 window: 16 of
         // 528 chains) is done group by group below instead of costing a second walk
         int nwalk = nchain - nchain % kBoundsThreads;
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             const int c = t / L.ngx, gx = t - c * L.ngx;
             if (c >= L.ndy) continue;
             const uint32_t *pp = P + (int64_t)(cy + L.dylo + c) * g.width + L.wx0 + 4 * gx;
-            const int64_t band = (int64_t)16 * g.width;
+            const int64_t band = (int64_t)S * g.width;
             uint32_t lb0[4];  // accumulator start: 0 for a legal member, 2^30 for one outside the picture
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -254,17 +264,17 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int kp = 0; kp < 2; kp++) bnd[j][kp] = *reinterpret_cast<const uint4 *>(pp + j * band + 32 * kp);
-            for (int m0 = 0; m0 < kMaxChain; m0 += 5)  // unrolled by the rotation period: static register indices
+                for (int kp = 0; kp < 2; kp++) bnd[j][kp] = *reinterpret_cast<const uint4 *>(pp + j * band + 2 * S * kp);
+            for (int m0 = 0; m0 < sea_max_chain(S); m0 += 5)  // unrolled by the rotation period: static register indices
 #pragma unroll
                 for (int mm = 0; mm < 5; mm++) {
                     const int m = m0 + mm;
-                    const int dyi = c + 16 * m;
+                    const int dyi = c + S * m;
                     if (dyi >= L.ndy) break;
-                    if (dyi + 16 < L.ndy) {
+                    if (dyi + S < L.ndy) {
 #pragma unroll
                         for (int kp = 0; kp < 2; kp++)
-                            bnd[(mm + 4) % 5][kp] = *reinterpret_cast<const uint4 *>(pp + (m + 4) * band + 32 * kp);
+                            bnd[(mm + 4) % 5][kp] = *reinterpret_cast<const uint4 *>(pp + (m + 4) * band + 2 * S * kp);
                     }
                     uint32_t lb[4] = {lb0[0], lb0[1], lb0[2], lb0[3]};
 #pragma unroll
@@ -289,19 +299,19 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         }
         // remainder chains, one group per lane: item i = (step m, chain r)
         const int nrem = nchain - nwalk;
-        const int nsteps = (L.ndy + 15) >> 4;
+        const int nsteps = (L.ndy + S - 1) / S;
         for (int i = tid; i < nrem * nsteps; i += kBoundsThreads) {
             const int m = i / nrem, t = nwalk + (i - m * nrem);
             const int c = t / L.ngx, gx = t - c * L.ngx;
-            const int dyi = c + 16 * m;
+            const int dyi = c + S * m;
             if (dyi >= L.ndy) continue;
             const uint32_t *pp = P + (int64_t)(cy + L.dylo + dyi) * g.width + L.wx0 + 4 * gx;
-            const int64_t band = (int64_t)16 * g.width;
+            const int64_t band = (int64_t)S * g.width;
             uint4 bnd[4][2];
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int kp = 0; kp < 2; kp++) bnd[j][kp] = *reinterpret_cast<const uint4 *>(pp + j * band + 32 * kp);
+                for (int kp = 0; kp < 2; kp++) bnd[j][kp] = *reinterpret_cast<const uint4 *>(pp + j * band + 2 * S * kp);
             uint32_t lb[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -392,19 +402,22 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             const int rr = plane - f * g.nrefs;
             const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
             const int x0 = L.wx0 + 4 * gx;
-            const uint32_t *rp = reinterpret_cast<const uint32_t *>(ref + (int64_t)(cy + L.dylo + dyi + lane) * g.stride + x0);
-            const uint32_t *cp = reinterpret_cast<const uint32_t *>(cur + (int64_t)(cy + lane) * g.stride + cx);
-            uint32_t d[17], cw[16];
+            constexpr int NW = B / 4;          // dwords of a block row
+            const int prow = lane < B ? lane : 0;  // a lane per block row (B = 32: the upper half of the wave adds nothing)
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(ref + (int64_t)(cy + L.dylo + dyi + prow) * g.stride + x0);
+            const uint32_t *cp = reinterpret_cast<const uint32_t *>(cur + (int64_t)(cy + prow) * g.stride + cx);
+            uint32_t d[NW + 1], cw[NW];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < NW; k++) {
                 d[k] = rp[k];
                 cw[k] = cp[k];
             }
-            d[16] = x0 + 68 <= g.width ? rp[16] : 0u;  // past the row end only members outside the picture read it
+            d[NW] = x0 + B + 4 <= g.width ? rp[NW] : 0u;  // past the row end only members outside the picture read it
             uint64_t acc16 = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++)
+            for (int k = 0; k < NW; k++)
                 acc16 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], cw[k], acc16);  // <= 16 * 1020 per lane
+            if (lane >= B) acc16 = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 uint32_t sq = (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
@@ -525,7 +538,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
 // comes from list0 with its entries already in registers when the window has landed; a second pass is
 // needed only if a group outside it has a bound <= the best SAD found (hdr.rest_min tells without a scan).
 // ---------------------------------------------------------------------------------------------
-template <bool kStats, int WAVES>
+template <bool kStats, int WAVES, int B>
 __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t *__restrict__ cur_base,
                                                                    const uint8_t *__restrict__ ref_base,
                                                                    const uint16_t *__restrict__ gl,
@@ -604,8 +617,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     const int plane = ctu_now / per_plane, cin = ctu_now - plane * per_plane;
     const int cty = cin / g.ctus_x, ctx = cin - cty * g.ctus_x;
     const int f = plane / g.nrefs, rr = plane - f * g.nrefs;
-    const int cx = ctx * 64, cy = cty * 64;
-    const SeaLayout L = sea_layout(g.width, g.height, R, cx, cy);
+    const int cx = ctx * B, cy = cty * B;
+    const SeaLayout L = sea_layout(g.width, g.height, R, cx, cy, B);
     const uint8_t *cur = cur_base + f * g.cur_fs;
     const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
     const uint16_t *glo = gl + ctu_id * gl_pitch;
@@ -659,36 +672,37 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx;
         uint32_t *pbuf = part[round & 1];
         if (__ballot(have) != 0ull) {  // wave-uniform
-            const uint32_t *wrow = win + (dyi + 16 * qtr) * L.pitch + gx;
-            const uint32_t *crow = cbase + (16 * qtr) * cstr;
+            constexpr int RQ = B / 4, NW = B / 4;  // rows of a quarter of the block, dwords of a block row
+            const uint32_t *wrow = win + (dyi + RQ * qtr) * L.pitch + gx;
+            const uint32_t *crow = cbase + (RQ * qtr) * cstr;
             uint32_t acc32[4] = {0u, 0u, 0u, 0u};
-            // two-row software pipeline: the loads of row r+1 (17 window dwords by ds_read2,
-            // 16 current dwords by s_load) are in flight while row r's sixteen qsads issue
-            uint32_t dA[17], dB[17], SA[16], SB[16];
+            // two-row software pipeline: the loads of row r+1 (NW + 1 window dwords by ds_read2,
+            // NW current dwords by s_load) are in flight while row r's NW qsads issue
+            uint32_t dA[NW + 1], dB[NW + 1], SA[NW], SB[NW];
             uint64_t acc16 = 0;
 #define SEA_LOAD(r, d, S)                                                   \
     {                                                                       \
         const uint32_t *p_ = wrow + (r) * L.pitch;                          \
-        _Pragma("unroll") for (int k = 0; k < 17; k++) d[k] = p_[k];        \
-        _Pragma("unroll") for (int k = 0; k < 16; k++) S[k] = crow[(r) * cstr + k]; \
+        _Pragma("unroll") for (int k = 0; k < NW + 1; k++) d[k] = p_[k];    \
+        _Pragma("unroll") for (int k = 0; k < NW; k++) S[k] = crow[(r) * cstr + k]; \
     }
 #define SEA_ROW(d, S)                                                                                   \
-    _Pragma("unroll") for (int k = 0; k < 16; k++)                                                     \
+    _Pragma("unroll") for (int k = 0; k < NW; k++)                                                     \
         acc16 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], S[k], acc16);
             SEA_LOAD(0, dA, SA)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
+            for (int r = 0; r < RQ; r += 2) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): row r has landed ...
                 SEA_LOAD(r + 1, dB, SB)              // ... row r+1 goes out before row r's qsads
                 __builtin_amdgcn_sched_barrier(0);
                 SEA_ROW(dA, SA)
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_waitcnt(0xc07f);
-                if (r + 2 < 16) SEA_LOAD(r + 2, dA, SA)
+                if (r + 2 < RQ) SEA_LOAD(r + 2, dA, SA)
                 __builtin_amdgcn_sched_barrier(0);
                 SEA_ROW(dB, SB)
                 __builtin_amdgcn_sched_barrier(0);
-                if ((r & 3) == 2) {  // every 4 rows: 64 qsads * 1020 < 2^16
+                if ((r & 3) == 2) {  // every 4 rows: at most 64 qsads * 1020 < 2^16
 #pragma unroll
                     for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
                     acc16 = 0;
@@ -827,9 +841,12 @@ static __device__ __align__(256) unsigned char sea_scratch[kSeaStaticBytes];
 
 int me_sea_device_setup(DeviceState &ds)
 {
-    const void *fns[] = {(const void *)sea_bounds_kernel, (const void *)sea_exact_kernel<false, 8>,
-                         (const void *)sea_exact_kernel<true, 8>, (const void *)sea_exact_kernel<false, 16>,
-                         (const void *)sea_exact_kernel<true, 16>};
+    const void *fns[] = {(const void *)sea_bounds_kernel<64>, (const void *)sea_exact_kernel<false, 8, 64>,
+                         (const void *)sea_exact_kernel<true, 8, 64>, (const void *)sea_exact_kernel<false, 16, 64>,
+                         (const void *)sea_exact_kernel<true, 16, 64>,
+                         (const void *)sea_bounds_kernel<32>, (const void *)sea_exact_kernel<false, 8, 32>,
+                         (const void *)sea_exact_kernel<true, 8, 32>, (const void *)sea_exact_kernel<false, 16, 32>,
+                         (const void *)sea_exact_kernel<true, 16, 32>};
     for (const void *fn : fns) {
         const int st = allow_full_lds(fn, ds);
         if (st != X265AMD_OK) return st;
@@ -880,16 +897,16 @@ extern "C" void x265amd_debug_sea_shape(int lds_pad_bytes, int waves)
 }
 
 // largest per-CTU geometry of a picture: rows / pitch of the window, groups per row, rows of candidates
-static void sea_extents(int width, int height, int range, int &max_rows, int &max_pitch, int &max_ngx, int &max_ndy)
+static void sea_extents(int width, int height, int range, int ctu, int &max_rows, int &max_pitch, int &max_ngx, int &max_ndy)
 {
     max_rows = max_pitch = max_ngx = max_ndy = 0;
-    for (int cy = 0; cy < height; cy += 64) {
-        const SeaLayout L = sea_layout(width, height, range, 0, cy);
+    for (int cy = 0; cy < height; cy += ctu) {
+        const SeaLayout L = sea_layout(width, height, range, 0, cy, ctu);
         max_rows = L.win_rows > max_rows ? L.win_rows : max_rows;
         max_ndy = L.ndy > max_ndy ? L.ndy : max_ndy;
     }
-    for (int cx = 0; cx < width; cx += 64) {
-        const SeaLayout L = sea_layout(width, height, range, cx, 0);
+    for (int cx = 0; cx < width; cx += ctu) {
+        const SeaLayout L = sea_layout(width, height, range, cx, 0, ctu);
         max_pitch = L.pitch > max_pitch ? L.pitch : max_pitch;
         max_ngx = L.ngx > max_ngx ? L.ngx : max_ngx;
     }
@@ -897,12 +914,13 @@ static void sea_extents(int width, int height, int range, int &max_rows, int &ma
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, int nframes, int nrefs)
+extern "C" size_t x265amd_me_workspace_bytes_ctu(int width, int height, int ctu, int range, int nframes, int nrefs)
 {
-    if (width <= 0 || height <= 0 || range < 0 || nframes <= 0 || nrefs <= 0 || width % 64 || height % 64) return 0;
+    if ((ctu != 64 && ctu != 32) || width <= 0 || height <= 0 || range < 0 || nframes <= 0 || nrefs <= 0 || width % ctu || height % ctu)
+        return 0;
     int max_rows, max_pitch, max_ngx, max_ndy;
-    sea_extents(width, height, range, max_rows, max_pitch, max_ngx, max_ndy);
-    const size_t planes = (size_t)nframes * nrefs, nctu = (size_t)(width / 64) * (height / 64);
+    sea_extents(width, height, range, ctu, max_rows, max_pitch, max_ngx, max_ndy);
+    const size_t planes = (size_t)nframes * nrefs, nctu = (size_t)(width / ctu) * (height / ctu);
     const size_t per_ctu = ((size_t)max_ngx * max_ndy + 7) & ~(size_t)7;  // 16-byte rows
     return align256(4 * (size_t)width * height * planes)                    // pair plane (u32) per (frame, ref) plane
            + 2 * align256(sizeof(uint16_t) * per_ctu * nctu * planes)      // bounds + first-batch list per CTU
@@ -910,6 +928,11 @@ extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, i
            + align256(sizeof(uint32_t) * kClasses * nctu * planes)         // launch-order queues of the exact kernel
            + 256                                                           // their counters
            + align256(sizeof(uint16_t) * per_ctu * kMaxWgLists);           // second-pass schedules of 16-wave workgroups
+}
+
+extern "C" size_t x265amd_me_workspace_bytes(int width, int height, int range, int nframes, int nrefs)
+{
+    return x265amd_me_workspace_bytes_ctu(width, height, 64, range, nframes, nrefs);
 }
 
 // workgroups of one exact-kernel variant that a CU holds at this dynamic-LDS size: asked once per device,
@@ -933,14 +956,14 @@ static int exact_per_cu(DeviceState &ds, const void *fn, int threads, size_t lds
 }
 
 // as many workgroups as the chip holds at once (LDS- and register-bound), each looping over CTUs
-template <int WAVES>
+template <int WAVES, int B>
 static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8_t *d_cur, const uint8_t *d_ref,
                         const uint16_t *gl, const uint16_t *list0, uint16_t *wg_list, const SeaHdr *hdr,
                         const uint32_t *order, uint32_t *ctrl, int total, x265amd_mv *d_out, const MeGeom &g, int gl_pitch,
                         int win_dwords)
 {
     uint32_t *const stats = g_me_stats;  // read once: the variant and its argument must agree
-    const void *fn = stats ? (const void *)sea_exact_kernel<true, WAVES> : (const void *)sea_exact_kernel<false, WAVES>;
+    const void *fn = stats ? (const void *)sea_exact_kernel<true, WAVES, B> : (const void *)sea_exact_kernel<false, WAVES, B>;
     int per_cu = 0;
     const int ost = exact_per_cu(ds, fn, WAVES * 64, lds, per_cu);
     if (ost != X265AMD_OK) return ost;
@@ -949,10 +972,10 @@ static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8
     if (WAVES == 16 && resident > kMaxWgLists) resident = kMaxWgLists;  // schedule slices in the workspace
     const dim3 grid((unsigned)(total < resident ? total : resident));
     if (stats)
-        hipLaunchKernelGGL((sea_exact_kernel<true, WAVES>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
+        hipLaunchKernelGGL((sea_exact_kernel<true, WAVES, B>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
                            hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, stats);
     else
-        hipLaunchKernelGGL((sea_exact_kernel<false, WAVES>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
+        hipLaunchKernelGGL((sea_exact_kernel<false, WAVES, B>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
                            hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, stats);
     return X265AMD_OK;
 }
@@ -964,8 +987,8 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
                       int64_t ref_ref_stride, x265amd_mv *d_out, void *d_workspace, size_t workspace_bytes, void *stream)
 {
     if (!d_cur || !d_ref || !d_out || !d_workspace) return X265AMD_ERR_ARG;
-    if (ctu != 64) return X265AMD_ERR_ARG;
-    if (width <= 0 || height <= 0 || width % 64 || height % 64 || stride < width) return X265AMD_ERR_ARG;
+    if (ctu != 64 && ctu != 32) return X265AMD_ERR_ARG;
+    if (width <= 0 || height <= 0 || width % ctu || height % ctu || stride < width) return X265AMD_ERR_ARG;
     if (range < 0 || range > 1024 || nframes < 0 || nrefs < 1) return X265AMD_ERR_ARG;
     if ((stride & 3) || ((uintptr_t)d_cur & 3) || ((uintptr_t)d_ref & 3) || (cur_frame_stride & 3) ||
         (ref_frame_stride & 3) || (ref_ref_stride & 3) || ((uintptr_t)d_workspace & 15))
@@ -973,13 +996,13 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     if (nframes == 0) return X265AMD_OK;
     const int64_t nplanes = (int64_t)nframes * nrefs;
     if (nplanes > 65535) return X265AMD_ERR_ARG;
-    if (workspace_bytes < x265amd_me_workspace_bytes(width, height, range, nframes, nrefs)) return X265AMD_ERR_ARG;
+    if (workspace_bytes < x265amd_me_workspace_bytes_ctu(width, height, ctu, range, nframes, nrefs)) return X265AMD_ERR_ARG;
 
     int max_rows, max_pitch, max_ngx, max_ndy;
-    sea_extents(width, height, range, max_rows, max_pitch, max_ngx, max_ndy);
+    sea_extents(width, height, range, ctu, max_rows, max_pitch, max_ngx, max_ndy);
     const int max_groups = max_ngx * max_ndy;
     const int gl_pitch = (max_groups + 7) & ~7;
-    if (max_groups > 0xffff || max_ndy > 16 * kMaxChain) return X265AMD_ERR_LDS;  // 16-bit schedule entries
+    if (max_groups > 0xffff || max_ndy > (ctu / 4) * sea_max_chain(ctu / 4)) return X265AMD_ERR_LDS;  // 16-bit schedule entries
     const int win_dwords = max_rows * max_pitch;
     const size_t list_bytes = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
     // 8-wave workgroups (window + schedule in LDS, 16 KB of partial sums) when two of them fit a CU;
@@ -993,7 +1016,7 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     if (!waves16 && lds8 + 17408 > lds_cap) return X265AMD_ERR_LDS;  // + the kernel's static LDS
     const size_t lds_bounds = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
 
-    const size_t nctu = (size_t)(width / 64) * (height / 64);
+    const size_t nctu = (size_t)(width / ctu) * (height / ctu);
     uint8_t *ws = (uint8_t *)d_workspace;
     uint32_t *pbuf = (uint32_t *)ws;  // pair plane (16-byte loads)
     ws += align256(4 * (size_t)width * height * (size_t)nplanes);
@@ -1012,8 +1035,14 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     hipStream_t st = (hipStream_t)stream;
     const bool timing = g_me_timing;
     if (timing) (void)hipEventRecord(g_me_ev[0], st);
-    hipLaunchKernelGGL(box16_pairs, dim3((width + kBoxTW - 1) / kBoxTW, (height - 15 + kBoxTH - 1) / kBoxTH, (unsigned)nplanes),
-                       dim3(256), 0, st, d_ref, pbuf, width, height, stride, nrefs, ref_frame_stride, ref_ref_stride, ctrl);
+    const int S = ctu / 4;  // sub-block side: rows y of the pair plane exist for y + S <= height
+    const dim3 box_grid((width + kBoxTW - 1) / kBoxTW, (height - (S - 1) + kBoxTH - 1) / kBoxTH, (unsigned)nplanes);
+    if (ctu == 64)
+        hipLaunchKernelGGL(box16_pairs<16>, box_grid, dim3(256), 0, st, d_ref, pbuf, width, height, stride, nrefs, ref_frame_stride,
+                           ref_ref_stride, ctrl);
+    else
+        hipLaunchKernelGGL(box16_pairs<8>, box_grid, dim3(256), 0, st, d_ref, pbuf, width, height, stride, nrefs, ref_frame_stride,
+                           ref_ref_stride, ctrl);
     if (timing) (void)hipEventRecord(g_me_ev[1], st);
     if (timing) (void)hipEventRecord(g_me_ev[2], st);
     MeGeom g;
@@ -1022,22 +1051,27 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     g.stride = stride;
     g.range = range;
     g.nrefs = nrefs;
-    g.ctus_x = width / 64;
-    g.ctus_y = height / 64;
+    g.ctus_x = width / ctu;
+    g.ctus_y = height / ctu;
     g.cur_fs = cur_frame_stride;
     g.ref_fs = ref_frame_stride;
     g.ref_rs = ref_ref_stride;
-    hipLaunchKernelGGL(sea_bounds_kernel, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
-                       d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, g_me_stats);
+    if (ctu == 64)
+        hipLaunchKernelGGL(sea_bounds_kernel<64>, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
+                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, g_me_stats);
+    else
+        hipLaunchKernelGGL(sea_bounds_kernel<32>, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
+                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, g_me_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;
-    if (waves16)
-        status = launch_exact<16>(ds, lds16, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch,
-                                  win_dwords);
+#define X265AMD_EXACT(WV, BB, LDS) \
+    launch_exact<WV, BB>(ds, LDS, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords)
+    if (ctu == 64)
+        status = waves16 ? X265AMD_EXACT(16, 64, lds16) : X265AMD_EXACT(8, 64, lds8);
     else
-        status = launch_exact<8>(ds, lds8, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch,
-                                 win_dwords);
+        status = waves16 ? X265AMD_EXACT(16, 32, lds16) : X265AMD_EXACT(8, 32, lds8);
+#undef X265AMD_EXACT
     if (status != X265AMD_OK) return status;
     if (timing) (void)hipEventRecord(g_me_ev[4], st);
     return hip_status(hipGetLastError());
@@ -1069,7 +1103,7 @@ extern "C" int x265amd_me_fullsearch_sea_static(const uint8_t *d_cur, const uint
     if (!ds) return X265AMD_ERR_NOT_INIT;
     if (!ds->sea_scratch) return X265AMD_ERR_NOT_INIT;
     if (nframes > 0 && nrefs > 0) {
-        const size_t need = x265amd_me_workspace_bytes(width, height, range, nframes, nrefs);
+        const size_t need = x265amd_me_workspace_bytes_ctu(width, height, ctu, range, nframes, nrefs);
         if (need == 0) return X265AMD_ERR_ARG;
         if (need > ds->sea_scratch_bytes) return X265AMD_ERR_WORKSPACE;  // beyond the static maximum: use _sea
     }
