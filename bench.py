@@ -520,13 +520,28 @@ def intra_frames(args, grp, nw, nh, cu, fps, qp):
                        "name": args.workload, "frames_per_step_per_gpu": fps},
             "roofline": {"kernel": "the whole step (intra_wave_kernel + tq_mfma_kernel x 2 per anti-diagonal)", "bound": "hbm",
                          "achieved": round(alg / (dev_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": intra_traffic(args.workload, nsteps),
                          "note": "algorithmic bytes = source + reconstruction + Int16 levels; the step is a chain of "
                                  f"{3 * nsteps} dependent launches of at most {fps} x {min(h // cu, (w // cu + 1) // 2)} workgroups, "
                                  "bound by that chain's latency, not by HBM or the VALU (DESIGN.md 4.6)"},
             "cpu_baseline": cpu,
         }), flush=True)
     grp.close()
+
+
+def intra_traffic(key, nsteps):
+    """bytes per step from the committed PMC passes: every dispatch of the step's kernels (per-dispatch averages x
+    dispatches) over the number of steps the counted run made (= dispatches of the prediction kernel / anti-diagonals)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            ks = json.load(f)[key]["kernels"]
+        pred = [k for k in ks if k.startswith("intra_wave_kernel")]
+        steps = sum(ks[k]["dispatches"] for k in pred) / nsteps
+        tot = sum(v["dispatches"] * (v["fetch_bytes_x2"] + v["write_bytes"]) for k, v in ks.items()
+                  if k.startswith(("intra_wave_kernel", "tq_mfma", "tq_kernel")))
+        return round(tot / steps)
+    except Exception:
+        return None
 
 
 def pmc_traffic(key, field):

@@ -36,6 +36,7 @@ pmc)
   for WL in 1080p 4k 8k4ref gop1080p tq1080p; do
     bash tools/run_pmc.sh $WL 3 1 $WL > $OUT/pmc_$WL.log 2>&1; echo "pmc $WL done"
   done
+  bash tools/run_pmc.sh intra1080p 2 1 intra1080p > $OUT/pmc_intra1080p.log 2>&1; echo "pmc intra1080p done"
   for TU in 16 8 4; do
     bash tools/run_pmc.sh tq1080p 3 1 tq1080p_tu$TU --tu $TU > $OUT/pmc_tq_tu$TU.log 2>&1; echo "pmc tq tu$TU done"
   done

@@ -177,6 +177,8 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     // blockIdx.y, cuy = diag_lo + blockIdx.x (the launcher sizes the grid; units that two CUs share are done twice,
     // to the same values)
     const bool diag = p.diag_count > 0;
+    // ... and of that unit only the tile that holds the CU: the other three waves of the workgroup load nothing and skip
+    const int only_tx = diag ? __builtin_amdgcn_readfirstlane(((p.diag_d - 2 * (p.diag_lo + (int)blockIdx.x)) << p.diag_cu_log2) >> 5) : -1;
     const int u_beg = diag ? 0 : blockIdx.x * per, u_end = diag ? 1 : min(u_beg + per, nunits);
     if (u_beg >= u_end) return;  // block-uniform; no barriers in this kernel
 
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     auto geo = [&](const TilePos &pos) {
         Geo g;
         const int tx = pos.txg * 4 + wave;
-        g.tile_ok = tx < p.tiles_x;                       // wave-uniform
+        g.tile_ok = tx < p.tiles_x && (only_tx < 0 || tx == only_tx);  // wave-uniform
         g.x0 = tx * 32;
         g.wvalid = g.tile_ok ? min(32, d.width - g.x0) : 0;  // a multiple of N
         g.xh = g.x0 + 16 * h;                             // the lane's 16 bytes of a picture row start here
