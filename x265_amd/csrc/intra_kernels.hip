@@ -120,6 +120,29 @@ template <int N, bool LUMA> __device__ __forceinline__ int intra_ang_pixel(const
     return p;
 }
 
+// Four neighbouring pixels of an angular mode at once.  Along the main index x (the column for the modes from 18 on, the
+// row below 18) the pixels x0 .. x0 + 3 of line k all have the same position idx / weight fact, so they are
+//   ((32 - fact) * m[a .. a + 3] + fact * m[a + 1 .. a + 4] + 16) >> 5,   a = N + x0 + idx + 1 in the mode's main row:
+// two aligned dwords of the row, two 64-bit shifts for the byte windows, even and odd bytes as packed u16 pairs (the
+// sums stay below 2^14), the four results back in one dword for v_sad_u8 against four source pixels.  fact = 0 gives
+// m[a ..] itself, as the reference's unweighted branch does.  (Modes 10 and 26: the caller smooths the first pixel.)
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t intra_ang_quad(const uint8_t *row, int a, int fact)
+{
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(row + (a & ~3));  // row is 4-byte aligned
+    const uint64_t win = ((uint64_t)w[1] << 32) | w[0];
+    const int sh = 8 * (a & 3);
+    const uint32_t A = (uint32_t)(win >> sh), Bq = (uint32_t)(win >> (sh + 8));
+    const uint32_t fp = (uint32_t)fact * 0x00010001u, gp = 0x00200020u - fp;
+    auto blend = [&](uint32_t x, uint32_t y) -> uint32_t {
+        const u16x2 r = (__builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, gp) + __builtin_bit_cast(u16x2, y) * __builtin_bit_cast(u16x2, fp) +
+                         __builtin_bit_cast(u16x2, 0x00100010u)) >> (unsigned short)5;
+        return __builtin_bit_cast(uint32_t, r);
+    };
+    const uint32_t even = blend(A & 0x00ff00ffu, Bq & 0x00ff00ffu), odd = blend((A >> 8) & 0x00ff00ffu, (Bq >> 8) & 0x00ff00ffu);
+    return even | (odd << 8);
+}
+
 // ---- pieces shared by the two kernels (one workgroup per CU) ----
 
 // the DC value of a sample array (src/encode.cpp:1398-1416), by wave 0; the caller puts a barrier after it
@@ -153,6 +176,48 @@ __device__ __forceinline__ void intra_luma_sads(const uint8_t (*s_ref)[kMaxRef +
             for (int t = 0; t < PER; t++) {
                 const int i = lane + 64 * t;
                 if (i < N * N) s = sad_acc((uint32_t)sp[t], (uint32_t)intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc), s);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) s_sad[mode] = s;
+    }
+}
+
+// The same for the frame kernel's 16 / 32 wide CUs, four pixels a step (intra_ang_quad): srcv[t] = the source pixels of
+// quad q = lane + 64 t read along rows (line k = q / (N / 4), x0 = 4 (q % (N / 4)): row k, columns x0 ..), srch[t] = the
+// same quad of the TRANSPOSED source (column k, rows x0 ..) -- a mode below 18 is the mirrored construction, so it is
+// compared against the transposed block.  Planar and DC take the pixel path.
+template <int N, int PER, int NWAVES>
+__device__ __forceinline__ void intra_luma_sads_quads(const uint8_t (*s_ref)[kMaxRef + 3], const int (&sp)[PER], const uint32_t (&srcv)[PER / 4],
+                                                      const uint32_t (&srch)[PER / 4], int dc, int wave, int lane, uint32_t *s_sad,
+                                                      uint8_t *main_row)
+{
+    constexpr int L2 = N == 16 ? 4 : 5;
+    constexpr int QL = N / 4;  // quads per line
+    for (int mode = wave; mode < 35; mode += NWAVES) {
+        const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][mode]];
+        uint32_t s = 0;
+        if (mode >= 2) {  // wave-uniform
+            intra_fill_main<N>(ref, mode, lane, main_row);
+            const int ang = kIntraAngle[mode];
+            const bool hor = mode < 18;
+#pragma unroll
+            for (int t = 0; t < PER / 4; t++) {
+                const int q = lane + 64 * t, k = q / QL, x0 = 4 * (q % QL);
+                const int pos = (k + 1) * ang;
+                uint32_t pq = intra_ang_quad(main_row, N + x0 + (pos >> 5) + 1, pos & 31);
+                if (ang == 0 && x0 == 0) {  // modes 10 and 26: the first pixel of a line follows the other side's gradient
+                    const uint8_t *tl = ref + 2 * N;
+                    const int p = (int)(pq & 0xffu) + ((tl[(hor ? 1 : -1) * (k + 1)] - tl[0]) >> 1);
+                    pq = (pq & 0xffffff00u) | (uint32_t)min(max(p, 0), 255);
+                }
+                s = __builtin_amdgcn_sad_u8(pq, hor ? srch[t] : srcv[t], s);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < PER; t++) {
+                const int i = lane + 64 * t;
+                s = sad_acc((uint32_t)sp[t], (uint32_t)intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc), s);
             }
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -298,7 +363,8 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
     }
     __shared__ uint8_t s_ref[2][kMaxRef + 3];
     __shared__ uint8_t s_refc[2][4 * 16 + 4];  // U, V: chroma reads the samples as they are
-    __shared__ uint8_t s_main[NWAVES][2][kMainRow];
+    __shared__ __attribute__((aligned(16))) uint8_t s_main[NWAVES][2][kMainRow];
+    __shared__ __attribute__((aligned(16))) uint8_t s_srcq[2][N][N + 4];  // the source CU, [row][column] and transposed
     __shared__ uint32_t s_sad[35], s_sadc[6];
     __shared__ int s_dc, s_dcc[2], s_best, s_bestc, s_mpm[3];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -325,8 +391,15 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
         sv[t] = f.d_src_v[o];
     }
     const int left_mode = (tid == NT - 1 && bL) ? f.d_mode_y[cu - 1] : 1;
+    // the source once more, a pixel per thread: laid out in LDS by rows and by columns, the quads of four pixels that
+    // intra_luma_sads_quads compares against are aligned dwords there whatever the plane's stride and address
+    const int tpix = tid < NPIX ? f.d_src_y[(int64_t)(y0 + (tid >> L2)) * f.stride_y + x0 + (tid & (N - 1))] : 0;
 
     // ---- reference samples: luma, and its smoothed copy; U and V ----
+    if (tid < NPIX) {
+        s_srcq[0][tid >> L2][tid & (N - 1)] = (uint8_t)tpix;
+        s_srcq[1][tid & (N - 1)][tid >> L2] = (uint8_t)tpix;
+    }
     if (tid <= 4 * N) s_ref[0][tid] = (uint8_t)intra_ref_sample(f.d_rec_y, f.stride_y, x0, y0, N, tid, bL, bT, bTR);
     for (int i = tid; i < 2 * (4 * NC + 1); i += NT) {
         const int pl = i >= 4 * NC + 1, j = i - pl * (4 * NC + 1);
@@ -360,7 +433,14 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
 
     // ---- luma decision ----
     const int dc = s_dc;
-    intra_luma_sads<N, PER, NWAVES>(s_ref, sp, dc, wave, lane, s_sad, s_main[wave][0]);
+    uint32_t srcv[PER / 4], srch[PER / 4];
+#pragma unroll
+    for (int t = 0; t < PER / 4; t++) {
+        const int q = lane + 64 * t;
+        srcv[t] = *reinterpret_cast<const uint32_t *>(&s_srcq[0][q / (N / 4)][4 * (q % (N / 4))]);
+        srch[t] = *reinterpret_cast<const uint32_t *>(&s_srcq[1][q / (N / 4)][4 * (q % (N / 4))]);
+    }
+    intra_luma_sads_quads<N, PER, NWAVES>(s_ref, sp, srcv, srch, dc, wave, lane, s_sad, s_main[wave][0]);
     __syncthreads();
     if (tid == 0) {
         const x265amd_intra_best b = intra_luma_argmin(s_sad, s_mpm[0], s_mpm[1], s_mpm[2], w.lambda);
