@@ -626,6 +626,7 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
     // U and V in one launch (one batch of planes) when all V planes continue the U planes' progression: a single
     // frame whose four V planes sit at one common distance behind their U planes (a 4:2:0 frame buffer), or a batch
     // stored plane-major (all U planes, then all V planes, one stride)
+    TqDiag pair{};  // plane grouping of the chroma launch (fgroup = 0: none)
     const int64_t du = f->d_src_v - f->d_src_u;
     const int64_t nu = (int64_t)(tu.height / tu.tu) * (tu.width / tu.tu);
     bool both = du > 0 && f->d_pred_v - f->d_pred_u == du && f->d_rec_v - f->d_rec_u == du &&
@@ -639,8 +640,20 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
             tu.abs_sum_frame_stride = f->d_abs_sum_u ? f->d_abs_sum_v - f->d_abs_sum_u : 0;
         }
     } else if (both) {
-        both = du == (int64_t)b.nframes * b.fs_c && (!f->d_abs_sum_u || f->d_abs_sum_v - f->d_abs_sum_u == (int64_t)b.nframes * b.fs_cu);
-        if (both) tu.nframes = 2 * b.nframes;
+        const bool plane_major = du == (int64_t)b.nframes * b.fs_c &&
+                                 (!f->d_abs_sum_u || f->d_abs_sum_v - f->d_abs_sum_u == (int64_t)b.nframes * b.fs_cu);
+        if (plane_major) {
+            tu.nframes = 2 * b.nframes;
+        } else if (b.fs_c % du == 0 && b.fs_c / du >= 2 && b.fs_c / du < 65536 && tq_takes_mfma(&tu)) {
+            // frame buffers one after the other (4:2:0: a frame is six chroma-plane sizes long): plane j of frame g is
+            // du * (g * fmul + j) behind the first U plane
+            pair.fgroup = 2;
+            pair.fmul = (int)(b.fs_c / du);
+            pair.sum_pair = f->d_abs_sum_u ? (long long)(f->d_abs_sum_v - f->d_abs_sum_u) : 0;
+            tu.src_frame_stride = tu.pred_frame_stride = tu.rec_frame_stride = tu.level_frame_stride = du;
+        } else {
+            both = false;
+        }
     }
     const int nw = x265amd_intra_waves(f);
     const int ncx = f->width / f->cu, ncy = f->height / f->cu;
@@ -650,7 +663,7 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
         // the transform stage follows the diagonal: only the tile units that hold its CUs
         const int lo = d - (ncx - 1) > 0 ? (d - (ncx - 1) + 1) / 2 : 0;
         const int hi = d / 2 < ncy - 1 ? d / 2 : ncy - 1;
-        const TqDiag dy{hi - lo + 1, d, lo, l2}, dc{hi - lo + 1, d, lo, l2 - 1};
+        const TqDiag dy{hi - lo + 1, d, lo, l2}, dc{hi - lo + 1, d, lo, l2 - 1, pair.fgroup, pair.fmul, pair.sum_pair};
         if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&ty, dy, stream);
         if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&tu, dc, stream);
         if (rc == X265AMD_OK && !both) rc = tq_roundtrip_diag(&tv, dc, stream);

@@ -19,6 +19,12 @@ struct TqParams {
     // x265amd_intra_encode_frame: only the tile units that hold the CUs of one anti-diagonal (cux + 2 cuy == diag_d,
     // cuy = diag_lo + blockIdx.x, CUs of 1 << diag_cu_log2 pixels in THIS plane); diag_count = 0: the whole plane
     int diag_count, diag_d, diag_lo, diag_cu_log2;
+    // .. for a batch of frames that hold `diag_fgroup` planes each (U and V of 4:2:0 frame buffers): blockIdx.y = g *
+    // diag_fgroup + j is plane j of frame g and sits d.*_frame_stride * (g * diag_fmul + j) behind the first plane (the
+    // frame strides are then the distance from one plane to the next inside a frame); its sums go to d_abs_sum +
+    // g * d.abs_sum_frame_stride + j * diag_sum_pair.  diag_fgroup = 0: blockIdx.y is the frame.
+    int diag_fgroup, diag_fmul;
+    long long diag_sum_pair;
 };
 
 enum { TQ_FWD = 1, TQ_INV = 2, TQ_BOTH = 3 };
@@ -29,7 +35,11 @@ int launch_tq_mfma(int mode, const TqParams &p, hipStream_t stream);
 // what x265amd_intra_encode_frame tells the transform stage about the anti-diagonal it follows
 struct TqDiag {
     int count, d, lo, cu_log2;
+    int fgroup = 0, fmul = 0;   // see TqParams::diag_fgroup; the descriptor's nframes is then the number of frames g
+    long long sum_pair = 0;
 };
+// whether launch_tq would take the matrix-core kernel for this descriptor (the only one that follows a diagonal)
+bool tq_takes_mfma(const x265amd_tq_desc *desc);
 // x265amd_tq_roundtrip restricted to the tile units of an anti-diagonal's CUs where the matrix-core kernel runs
 // (the whole plane otherwise: the result is the same, see intra_kernels.hip)
 int tq_roundtrip_diag(const x265amd_tq_desc *desc, const TqDiag &diag, hipStream_t stream);

@@ -440,11 +440,16 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     p.trace_waves = g_tq_trace_waves;
     p.diag_count = 0;
     p.diag_d = p.diag_lo = p.diag_cu_log2 = 0;
+    p.diag_fgroup = p.diag_fmul = 0;
+    p.diag_sum_pair = 0;
     if (diag && diag->count > 0) {
         p.diag_count = diag->count;
         p.diag_d = diag->d;
         p.diag_lo = diag->lo;
         p.diag_cu_log2 = diag->cu_log2;
+        p.diag_fgroup = diag->fgroup;
+        p.diag_fmul = diag->fmul;
+        p.diag_sum_pair = diag->sum_pair;
     }
     if (coef_in) {  // the plane already holds xDeQuant's output: (c * 1 + 0) >> 0, and the clip is a no-op on Int16
         p.dq_scale = 1;
@@ -455,10 +460,8 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     // plane and the rows split into 16-byte pieces; per-TU DST selection at 4x4 (d_modes), widths that are not a
     // multiple of 16 and the debug switch keep the butterfly kernel
     // .. and so do planes whose strides or height do not fit the 24-bit multiplies of its address arithmetic
-    const int kLim = 1 << 23;
-    const bool small = d.height < kLim && d.level_stride < kLim && d.pred_stride < kLim && d.src_stride < kLim &&
-                       d.rec_stride < kLim;
-    if (g_tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0 && small) return launch_tq_mfma(MODE, p, stream);
+    if (tq_takes_mfma(desc)) return launch_tq_mfma(MODE, p, stream);
+    if (p.diag_fgroup) return X265AMD_ERR_ARG;  // plane groups exist in the matrix-core kernel only (callers ask tq_takes_mfma first)
     const dim3 grid((unsigned)((nt + 7) / 8)), block(256);
     switch (d.tu) {
     case 4: hipLaunchKernelGGL((tq_kernel<4, MODE>), grid, block, 0, stream, p); break;
@@ -467,6 +470,15 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     default: hipLaunchKernelGGL((tq_kernel<32, MODE>), grid, block, 0, stream, p); break;
     }
     return hip_status(hipGetLastError());
+}
+
+bool tq_takes_mfma(const x265amd_tq_desc *desc)
+{
+    const x265amd_tq_desc &d = *desc;
+    const int kLim = 1 << 23;
+    const bool small = d.height < kLim && d.level_stride < kLim && d.pred_stride < kLim && d.src_stride < kLim &&
+                       d.rec_stride < kLim;
+    return g_tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0 && small;
 }
 
 int tq_roundtrip_diag(const x265amd_tq_desc *desc, const TqDiag &diag, hipStream_t stream)

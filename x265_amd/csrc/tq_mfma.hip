@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
         pos0.txg = rem - pos0.ty * ntxg;
         if (diag) {
             const int cuy = p.diag_lo + (int)blockIdx.x, cux = p.diag_d - 2 * cuy;
-            pos0.f = (int)blockIdx.y;
+            pos0.f = p.diag_fgroup ? ((int)blockIdx.y / p.diag_fgroup) * p.diag_fmul + (int)blockIdx.y % p.diag_fgroup : (int)blockIdx.y;
             pos0.ty = (cuy << p.diag_cu_log2) >> 5;
             pos0.txg = ((cux << p.diag_cu_log2) >> 5) >> 2;
         }
@@ -441,7 +441,10 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
                 }
                 // one lane per TU column writes; TU rows below the picture are past the end of the resource
                 const __amdgpu_buffer_rsrc_t sum_rs = __builtin_amdgcn_make_buffer_rsrc(
-                    d.d_abs_sum + (int64_t)f * d.abs_sum_frame_stride, 0, (uint32_t)((d.height >> L2) * (d.width >> L2)) * 4u, kRsrcFlags);
+                    d.d_abs_sum + (p.diag_fgroup ? (int64_t)((int)blockIdx.y / p.diag_fgroup) * d.abs_sum_frame_stride +
+                                                       (int64_t)((int)blockIdx.y % p.diag_fgroup) * p.diag_sum_pair
+                                                 : (int64_t)f * d.abs_sum_frame_stride),
+                    0, (uint32_t)((d.height >> L2) * (d.width >> L2)) * 4u, kRsrcFlags);
                 const bool writer = (N == 32 ? lane == 63 : (c & (N - 1)) == 0 && (N == 4 || h == 0)) && col_ok;
                 const uint32_t a_off = writer ? (uint32_t)((y0 >> L2) * tus_x + ((x0 + c) >> L2)) * 4u : kOob;
 #pragma unroll
@@ -569,8 +572,11 @@ int launch_tq_mfma(int mode, const TqParams &p_in, hipStream_t stream)
         if (p.diag_cu_log2 < 3 || p.diag_cu_log2 > 5 || p.diag_lo < 0 || (hi + 1) * cu > p.d.height || p.diag_d - 2 * hi < 0 ||
             (p.diag_d - 2 * p.diag_lo + 1) * cu > p.d.width || p.d.nframes > 65535)
             return X265AMD_ERR_ARG;
-        nwg = (int64_t)p.diag_count * p.d.nframes;
-        grid = dim3((unsigned)p.diag_count, (unsigned)p.d.nframes);
+        if (p.diag_fgroup < 0 || (p.diag_fgroup > 0 && (p.diag_fmul < p.diag_fgroup || (int64_t)p.d.nframes * p.diag_fgroup > 65535)))
+            return X265AMD_ERR_ARG;
+        const int ny = p.diag_fgroup ? p.d.nframes * p.diag_fgroup : p.d.nframes;
+        nwg = (int64_t)p.diag_count * ny;
+        grid = dim3((unsigned)p.diag_count, (unsigned)ny);
     }
     if (p.trace_waves < nwg * 4) p.d_trace = nullptr;
     if (mode == TQ_FWD)
