@@ -296,6 +296,13 @@ def test_me_sea_equals_exhaustive_on_hostile_content(gpu):
     cases.append((a, np.ascontiguousarray(b[::-1]), 64))
     seq = synth.make_sequence(640, 384, 2, search_range=64, seed=5)
     cases.append((seq[1], seq[0], 64))
+    # +-128: the 16-wave shape, whose second pass drops groups on the SAD of the block's upper half -- noise (every
+    # group outlives it: the kept list is drained again and again), flat (all tie), and real motion
+    cases.append((rng.integers(0, 256, (320, 384), dtype=np.uint8), rng.integers(0, 256, (320, 384), dtype=np.uint8), 128))
+    flat2 = np.full((256, 320), 200, np.uint8)
+    cases.append((flat2, flat2.copy(), 128))
+    seq = synth.make_sequence(512, 384, 2, search_range=128, seed=9)
+    cases.append((seq[1], seq[0], 128))
     for cur, ref, r in cases:
         for ctu in (64, 32):
             x = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, r, method="brute"))

@@ -29,6 +29,11 @@ for i, n in bnames.items():
     print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
 interior = [i for i in range(nctu_all) if 2 <= (i % nctu) % (W // 64) <= W // 64 - 3 and 2 <= (i % nctu) // (W // 64) <= H // 64 - 3]
 print("interior CTUs:", {n: float(s[interior, i].mean()) for i, n in enumerate(names)})
+if s[:, 14].any():
+    m = s[:, 1] > 0
+    print("second pass, 16-wave shape: groups that outlive their upper half: mean %.1f of %.1f scheduled (%.0f %%)" %
+          (s[m, 14].mean(), s[m, 1].mean(), 100.0 * s[m, 14].sum() / max(s[m, 1].sum(), 1)))
+    print("  best SAD after the first batch vs final: ", "n/a")
 print("CTUs with a second pass:", int((s[:, 1] > 0).sum()), "of", nctu_all,
       "| rounds per CTU (mean):", float((np.ceil(s[:, 0] / 128) + np.ceil(s[:, 1] / 128)).mean()))
 print("pass-1 sizes, fine (1-4, 5-8, 9-16, 17-32, 33-64):",

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                                                                    const uint32_t *__restrict__ order,
                                                                    uint32_t *__restrict__ ctrl, int total,
                                                                    x265amd_mv *__restrict__ out, const MeGeom g,
-                                                                   int gl_pitch, int win_dwords,
+                                                                   int gl_pitch, int win_dwords, int surv_cap,
                                                                    uint32_t *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -560,7 +560,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     uint16_t *list = WAVES == 8 ? reinterpret_cast<uint16_t *>(smem + win_dwords) : wg_list + (size_t)blockIdx.x * gl_pitch;
     __shared__ __attribute__((aligned(16))) uint32_t part[2][WAVES * 64 * 4];  // partial SADs: [round & 1][wave][lane][4 dx]
     __shared__ unsigned long long best_key;
-    __shared__ int list_n, next_ctu;
+    __shared__ int list_n, next_ctu, surv_n;
+    // 16-wave shape, second pass: groups that outlived the upper half of the block (see below), behind the window
+    [[maybe_unused]] uint32_t *surv_sum = smem + ((win_dwords + 3) & ~3);                        // [surv_cap][4] upper-half SADs
+    [[maybe_unused]] uint16_t *surv_ent = reinterpret_cast<uint16_t *>(surv_sum + 4 * surv_cap);  // [surv_cap] their groups
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: keeps the current rows in SGPRs
@@ -708,8 +711,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                     acc16 = 0;
                 }
             }
-#undef SEA_LOAD
-#undef SEA_ROW
             *reinterpret_cast<uint4 *>(&pbuf[(wave * 64 + lane) * 4]) = make_uint4(acc32[0], acc32[1], acc32[2], acc32[3]);
         }
         __syncthreads();
@@ -746,6 +747,56 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         round++;  // the next round writes the other half of part[]: no second barrier
     };
 
+    // ---- half rounds (16-wave shape, second pass).  Every group of the second pass has a bound under the best SAD,
+    //      but on content whose candidates differ by pixel noise most of them lose by a wide margin: their SAD over
+    //      the UPPER HALF of the block alone already exceeds the best SAD, and a partial SAD is a lower bound of the
+    //      whole one, so they can be dropped there -- exactly as a bound drops them (no winner, no tie is lost).  A half
+    //      round = 2 x kRound groups: a wave takes 64 groups x the B / 4 rows of one quarter of ONE half; the groups
+    //      whose upper half stays under the best SAD of the first batch are kept with their four partial SADs and
+    //      finished by lower-half rounds. ----
+    [[maybe_unused]] auto half_partial = [&](int ent, bool have, int row0) {
+        ent = have ? ent : 0;
+        const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx;
+        uint32_t *pbuf = part[round & 1];
+        if (__ballot(have) != 0ull) {  // wave-uniform
+            constexpr int RQ = B / 4, NW = B / 4;
+            const uint32_t *wrow = win + (dyi + row0) * L.pitch + gx;
+            const uint32_t *crow = cbase + row0 * cstr;
+            uint32_t acc32[4] = {0u, 0u, 0u, 0u};
+            uint32_t dA[NW + 1], dB[NW + 1], SA[NW], SB[NW];
+            uint64_t acc16 = 0;
+            SEA_LOAD(0, dA, SA)
+#pragma unroll
+            for (int r = 0; r < RQ; r += 2) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                SEA_LOAD(r + 1, dB, SB)
+                __builtin_amdgcn_sched_barrier(0);
+                SEA_ROW(dA, SA)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (r + 2 < RQ) SEA_LOAD(r + 2, dA, SA)
+                __builtin_amdgcn_sched_barrier(0);
+                SEA_ROW(dB, SB)
+                __builtin_amdgcn_sched_barrier(0);
+                if ((r & 3) == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
+                    acc16 = 0;
+                }
+            }
+            *reinterpret_cast<uint4 *>(&pbuf[(wave * 64 + lane) * 4]) = make_uint4(acc32[0], acc32[1], acc32[2], acc32[3]);
+        }
+    };
+#undef SEA_LOAD
+#undef SEA_ROW
+    // the two quarters of a half that the waves `wave` and `wave + 1` left in part[]
+    [[maybe_unused]] auto half_sum = [&]() -> uint4 {
+        const uint32_t *pbuf = part[round & 1];
+        const uint4 a = *reinterpret_cast<const uint4 *>(&pbuf[(wave * 64 + lane) * 4]);
+        const uint4 b = *reinterpret_cast<const uint4 *>(&pbuf[((wave + 1) * 64 + lane) * 4]);
+        return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    };
+
     // ---- pass 0: the first batch ----
 #pragma unroll
     for (int r = 0; r < kFirst / kRound; r++)
@@ -755,6 +806,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     const long long t_pass0 = kStats ? clock64() : 0;
     // ---- pass 1, only if some group left over has a bound <= the best SAD so far ----
     int n1 = 0;
+    [[maybe_unused]] int n_kept = 0;  // (statistics) groups of the second pass that outlived their upper half
     const uint32_t best_sad = (uint32_t)(best_key >> 32);
     if (rest_min != kNone && (rest_min << 4) <= best_sad) {
         // one sweep: a thread takes 8 consecutive bounds (one 16-byte load, all of a CTU's loads in flight at
@@ -789,10 +841,98 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         }
         __syncthreads();
         n1 = list_n;
-        for (int base = 0; base < n1; base += kRound) {
-            const int li = base + set * 64 + lane;
-            const bool have = li < n1;
-            run_round((int)list[have ? li : 0], have);
+        if constexpr (WAVES != 16) {
+            for (int base = 0; base < n1; base += kRound) {
+                const int li = base + set * 64 + lane;
+                const bool have = li < n1;
+                run_round((int)list[have ? li : 0], have);
+            }
+        } else {
+            // half rounds (see half_partial): upper halves over the schedule, the groups that stay under the best SAD
+            // of the first batch are kept; whenever the kept list could not take another half round's worth -- and at
+            // the end -- lower halves over the kept groups finish them.  One loop, one copy of the row code.
+            constexpr int kHalf = 2 * kRound;           // groups of a half round
+            const int hset = wave >> 1, hq = wave & 1;  // 64 groups a set; the two quarters of a half
+            if (tid == 0) surv_n = 0;
+            __syncthreads();
+            int base = 0, kbase = 0, nk = 0;
+            bool lower = false;
+            for (;;) {
+                // the threshold follows the search: every lower-half round may have brought a better SAD
+                const uint32_t cur_best = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
+                if (!lower) {
+                    const int kept = surv_n;  // uniform: read between barriers
+                    // finish what is kept as soon as it fills half a round (a better best SAD prunes what follows), when
+                    // the list could not take another half round's worth, and at the end
+                    if (base >= n1 || kept >= kHalf / 2 || kept + kHalf > surv_cap) {
+                        lower = true;
+                        nk = kept;
+                        kbase = 0;
+                        if constexpr (kStats) n_kept += kept;
+                    }
+                }
+                if (lower && kbase >= nk) {
+                    if (base >= n1) break;
+                    if (tid == 0) surv_n = 0;  // the kept groups are finished: collect again
+                    __syncthreads();
+                    lower = false;
+                    continue;
+                }
+                const int li = (lower ? kbase : base) + hset * 64 + lane;
+                const bool have = li < (lower ? nk : n1);
+                const int ent = have ? (int)(lower ? surv_ent[li] : list[li]) : 0;
+                half_partial(ent, have, (lower ? B / 2 : 0) + (B / 4) * hq);
+                __syncthreads();
+                if (hq == 0 && __ballot(have) != 0ull) {
+                    unsigned long long k = ~0ull;
+                    bool keep = false;
+                    uint4 sm = make_uint4(0u, 0u, 0u, 0u);
+                    if (have) {
+                        const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx, dy = L.dylo + dyi;
+                        sm = half_sum();
+                        if (lower) {
+                            const uint4 up = *reinterpret_cast<const uint4 *>(&surv_sum[4 * li]);
+                            sm = make_uint4(sm.x + up.x, sm.y + up.y, sm.z + up.z, sm.w + up.w);
+                        }
+                        const uint32_t sad[4] = {sm.x, sm.y, sm.z, sm.w};
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int dx = L.wx0 - cx + 4 * gx + q;
+                            if (dx >= L.dxlo && dx <= L.dxhi) {
+                                const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
+                                k = key < k ? key : k;
+                                keep = keep || sad[q] <= cur_best;
+                            }
+                        }
+                    }
+                    if (lower) {  // wave-uniform
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const unsigned long long other = __shfl_xor(k, o);
+                            k = other < k ? other : k;
+                        }
+                        if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
+                    } else {
+                        const unsigned long long km = __ballot(keep);
+                        if (km != 0ull) {
+                            int wbase = 0;
+                            if (lane == 0) wbase = atomicAdd(&surv_n, __popcll(km));
+                            wbase = __shfl(wbase, 0);
+                            if (keep) {
+                                const int slot = wbase + __popcll(km & ((1ull << lane) - 1ull));
+                                surv_ent[slot] = (uint16_t)ent;
+                                *reinterpret_cast<uint4 *>(&surv_sum[4 * slot]) = sm;
+                            }
+                        }
+                    }
+                }
+                round++;
+                if (lower)
+                    kbase += kHalf;
+                else
+                    base += kHalf;
+                __syncthreads();  // surv_n and the kept entries are visible; part[] may be written again
+            }
         }
         __syncthreads();
     }
@@ -814,6 +954,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             stats[16 * ctu_id + 5] = (uint32_t)t_begin;               // absolute, low 32 bits
             stats[16 * ctu_id + 6] = (uint32_t)t_end;
             stats[16 * ctu_id + 8] = h.est;
+            stats[16 * ctu_id + 14] = (uint32_t)n_kept;
             stats[16 * ctu_id + 9] = (uint32_t)blockIdx.x;
             stats[16 * ctu_id + 7] = (__builtin_amdgcn_s_getreg(63492) & 0xffffu) | (__builtin_amdgcn_s_getreg(6164) << 16);  // HW_ID | XCC_ID
         }
@@ -960,7 +1101,7 @@ template <int WAVES, int B>
 static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8_t *d_cur, const uint8_t *d_ref,
                         const uint16_t *gl, const uint16_t *list0, uint16_t *wg_list, const SeaHdr *hdr,
                         const uint32_t *order, uint32_t *ctrl, int total, x265amd_mv *d_out, const MeGeom &g, int gl_pitch,
-                        int win_dwords)
+                        int win_dwords, int surv_cap)
 {
     uint32_t *const stats = g_me_stats;  // read once: the variant and its argument must agree
     const void *fn = stats ? (const void *)sea_exact_kernel<true, WAVES, B> : (const void *)sea_exact_kernel<false, WAVES, B>;
@@ -973,10 +1114,10 @@ static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8
     const dim3 grid((unsigned)(total < resident ? total : resident));
     if (stats)
         hipLaunchKernelGGL((sea_exact_kernel<true, WAVES, B>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
-                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, stats);
+                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, surv_cap, stats);
     else
         hipLaunchKernelGGL((sea_exact_kernel<false, WAVES, B>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
-                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, stats);
+                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, surv_cap, stats);
     return X265AMD_OK;
 }
 
@@ -1008,11 +1149,24 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     // 8-wave workgroups (window + schedule in LDS, 16 KB of partial sums) when two of them fit a CU;
     // otherwise ONE 16-wave workgroup per CU (window only + 32 KB of partial sums, schedule in the workspace)
     const size_t lds8 = (size_t)win_dwords * 4 + list_bytes + (size_t)g_sea_lds_pad;
-    const size_t lds16 = (size_t)win_dwords * 4;
+    size_t lds16 = (size_t)win_dwords * 4;
     const size_t lds_cap = (size_t)ds.lds_limit;
     bool waves16 = 2 * (lds8 + 17408) > lds_cap;
     if (g_sea_waves) waves16 = g_sea_waves == 16;
     if (waves16 && lds16 + 33792 > lds_cap) waves16 = false;
+    // 16-wave shape: what is left of the LDS holds the groups that outlive the upper half of the block in the second
+    // pass (18 bytes each; at least two half rounds' worth = 1024, else the second pass runs whole rounds)
+    int surv_cap = 0;
+    if (waves16) {
+        const size_t base = (((size_t)win_dwords + 3) & ~(size_t)3) * 4;
+        const size_t room = lds_cap > base + 33792 + 64 ? lds_cap - base - 33792 - 64 : 0;
+        const size_t cap = (room / 18) & ~(size_t)511;
+        if (cap >= 1024) {
+            surv_cap = (int)(cap > 4096 ? 4096 : cap);
+            lds16 = base + (size_t)surv_cap * 18;
+        }
+    }
+    if (waves16 && surv_cap == 0) return X265AMD_ERR_LDS;  // the second pass of the 16-wave shape needs its kept list
     if (!waves16 && lds8 + 17408 > lds_cap) return X265AMD_ERR_LDS;  // + the kernel's static LDS
     const size_t lds_bounds = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
 
@@ -1066,7 +1220,7 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;
 #define X265AMD_EXACT(WV, BB, LDS) \
-    launch_exact<WV, BB>(ds, LDS, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords)
+    launch_exact<WV, BB>(ds, LDS, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, surv_cap)
     if (ctu == 64)
         status = waves16 ? X265AMD_EXACT(16, 64, lds16) : X265AMD_EXACT(8, 64, lds8);
     else
