@@ -861,3 +861,22 @@ def test_me_sea_32x32_blocks_1080p(gpu, oracle):
         want = oracle.me_fullsearch(seq[f + 1], seq[f], 32, R, first=5 + f, step=211, nthreads=8)   # every 211th block
         idx = np.arange(5 + f, a.shape[2], 211)
         np.testing.assert_array_equal(a[f, 0][idx], want[idx], f"frame {f}")
+
+
+def test_intra_api_rejects_wrong_output_buffers(gpu):
+    """a caller's `out` of another shape, type or layout is refused before anything is launched (the library writes
+    through those pointers)"""
+    from x265_amd import api, synth
+    w, h, cu = 64, 32, 16
+    yuv = dev(synth.make_intra_probe(w, h, 2))
+    good = gpu.intra_encode_frames(yuv, w, h, cu, 30)
+    for k, bad in (("level", good["level"].to(torch.int32)), ("rec", good["rec"][:, :-1]), ("mode_y", good["mode_y"][:1]),
+                   ("pred", good["pred"].t().contiguous().t())):
+        with pytest.raises(ValueError):
+            gpu.intra_encode_frames(yuv, w, h, cu, 30, out=dict(good, **{k: bad}))
+    with pytest.raises(ValueError):
+        gpu.intra_encode_frames(yuv, w, h, cu, 30, out={k: v for k, v in good.items() if k != "cost_c"})
+    y, u, v = yuv[0, :w * h].view(h, w), yuv[0, w * h:w * h * 5 // 4].view(h // 2, w // 2), yuv[0, w * h * 5 // 4:].view(h // 2, w // 2)
+    one = api.intra_frame_buffers(h, w, cu, y.device)
+    with pytest.raises(ValueError):
+        gpu.intra_encode_frame(y.contiguous(), u.contiguous(), v.contiguous(), cu, 30, out=dict(one, level_u=one["level_y"]))

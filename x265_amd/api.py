@@ -372,6 +372,17 @@ def intra_decide_luma(src, xy, size, ref, mpm, lam, want_sads=False, want_pred=F
     return best, sads, pred
 
 
+def _check_out(out, spec, device):
+    """the library writes through these pointers: a buffer of another size, type, layout or device would be written
+    past its end, so a caller's `out` is checked field by field before anything is launched"""
+    if set(out) != set(spec):
+        raise ValueError(f"out: need exactly the buffers {sorted(spec)}")
+    for k, (shape, dtype) in spec.items():
+        t = out[k]
+        if not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != dtype or not t.is_contiguous() or t.device != device:
+            raise ValueError(f"out[{k!r}]: need a contiguous {dtype} tensor of shape {tuple(shape)} on {device}")
+
+
 class IntraFrame(C.Structure):
     """include/x265_amd.h: x265amd_intra_frame"""
     _fields_ = ([("width", C.c_int32), ("height", C.c_int32), ("cu", C.c_int32), ("qp", C.c_int32),
@@ -414,6 +425,13 @@ def intra_encode_frame(y, u, v, cu, qp, wave_by_wave=False, out=None):
     ncus = (h // cu) * (w // cu) if cu in (16, 32) else 0
     dv = y.device
     o = out if out is not None else intra_frame_buffers(h, w, cu, dv)
+    hc, wc = h // 2, w // 2
+    _check_out(o, {"rec_y": ((h, w), torch.uint8), "rec_u": ((hc, wc), torch.uint8), "rec_v": ((hc, wc), torch.uint8),
+                   "pred_y": ((h, w), torch.uint8), "pred_u": ((hc, wc), torch.uint8), "pred_v": ((hc, wc), torch.uint8),
+                   "level_y": ((h, w), torch.int16), "level_u": ((hc, wc), torch.int16), "level_v": ((hc, wc), torch.int16),
+                   "mode_y": ((ncus,), torch.uint8), "mode_c": ((ncus,), torch.uint8),
+                   "cost_y": ((ncus,), torch.int32), "cost_c": ((ncus,), torch.int32), "abs_sum_y": ((ncus,), torch.int32),
+                   "abs_sum_u": ((ncus,), torch.int32), "abs_sum_v": ((ncus,), torch.int32)}, dv)
     f = IntraFrame()
     f.width, f.height, f.cu, f.qp, f.stride_y, f.stride_c = w, h, cu, qp, w, w // 2
     f.d_src_y, f.d_src_u, f.d_src_v = y.data_ptr(), u.data_ptr(), v.data_ptr()
@@ -454,6 +472,11 @@ def intra_encode_frames(yuv, width, height, cu, qp, out=None):
                "level": torch.zeros((n, fsz), dtype=torch.int16, device=dv),
                "mode_y": torch.zeros((n, ncus), dtype=torch.uint8, device=dv), "mode_c": torch.zeros((n, ncus), dtype=torch.uint8, device=dv),
                "cost_y": zi(), "cost_c": zi(), "abs_sum_y": zi(), "abs_sum_u": zi(), "abs_sum_v": zi()}
+    _check_out(out, {"rec": ((n, fsz), torch.uint8), "pred": ((n, fsz), torch.uint8), "level": ((n, fsz), torch.int16),
+                     "mode_y": ((n, ncus), torch.uint8), "mode_c": ((n, ncus), torch.uint8),
+                     "cost_y": ((n, ncus), torch.int32), "cost_c": ((n, ncus), torch.int32),
+                     "abs_sum_y": ((n, ncus), torch.int32), "abs_sum_u": ((n, ncus), torch.int32),
+                     "abs_sum_v": ((n, ncus), torch.int32)}, dv)
     f = IntraFrame()
     f.width, f.height, f.cu, f.qp, f.stride_y, f.stride_c = w, h, cu, qp, w, w // 2
     ysz, csz = w * h, w * h // 4
