@@ -261,6 +261,9 @@ def me_fullsearch(cur, ref, ctu=64, search_range=64, out=None, method="auto", wo
     nctu = (h // ctu) * (w // ctu) if ctu > 0 else 0
     if out is None:
         out = torch.empty((f, nrefs, max(nctu, 0), 2), dtype=torch.int32, device=cur.device)
+    _dev(out, torch.int32, "out")
+    if not out.is_contiguous() or out.numel() < f * nrefs * max(nctu, 0) * 2:
+        raise ValueError("out: need a contiguous int32 tensor of at least [F][R][nctu][2] elements")
     if method not in ("auto", "brute", "sea", "sea_static", "basic"):
         raise ValueError("method")
     if method == "sea_static":
@@ -577,6 +580,8 @@ def _tq_desc(tu, qp, slice_type, src=None, pred=None, mv=None, mv_ctu=64, modes=
         d.d_coef = cp
     if abs_sum is not None:
         _dev(abs_sum, torch.int32, "abs_sum")
+        if tu > 0 and (not abs_sum.is_contiguous() or abs_sum.numel() < f * (h // tu) * (w // tu)):
+            raise ValueError("abs_sum: need a contiguous int32 tensor of at least [F][TUs per plane] elements")
         d.d_abs_sum, d.abs_sum_frame_stride = abs_sum.data_ptr(), (h // tu) * (w // tu)
     if rec is not None:
         d.d_rec, rf, rh, rw, d.rec_stride, d.rec_frame_stride = _planes(rec, torch.uint8, "rec")
