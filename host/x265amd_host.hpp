@@ -98,7 +98,7 @@ class GopEncoder {
     int poc() const { return poc_; }
     bool exhaustive_fallback() const { return brute_; }
 
-    // The reconstruction of each segment's I picture, made by the host (intra prediction is outside this path).
+    // The reconstruction of each segment's I picture when it is made elsewhere (encode_i below makes it here).
     void set_reference(const uint8_t *yuv)
     {
         check(x265amd_memcpy_h2d(refn_[kMaxRefNum]->as(), yuv, fsz_ * nseg_, stream_), "x265amd_memcpy_h2d");
