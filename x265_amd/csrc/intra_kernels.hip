@@ -655,6 +655,9 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
             both = false;
         }
     }
+    // the whole transform stage of a step as one launch where U and V already share theirs and every plane takes the
+    // matrix-core kernel (luma width a multiple of 32: the chroma width must be one of 16)
+    const bool one_launch = both && tq_takes_mfma(&ty) && tq_takes_mfma(&tu);
     const int nw = x265amd_intra_waves(f);
     const int ncx = f->width / f->cu, ncy = f->height / f->cu;
     const int l2 = f->cu == 16 ? 4 : 5;
@@ -664,9 +667,13 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
         const int lo = d - (ncx - 1) > 0 ? (d - (ncx - 1) + 1) / 2 : 0;
         const int hi = d / 2 < ncy - 1 ? d / 2 : ncy - 1;
         const TqDiag dy{hi - lo + 1, d, lo, l2}, dc{hi - lo + 1, d, lo, l2 - 1, pair.fgroup, pair.fmul, pair.sum_pair};
-        if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&ty, dy, stream);
-        if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&tu, dc, stream);
-        if (rc == X265AMD_OK && !both) rc = tq_roundtrip_diag(&tv, dc, stream);
+        if (rc == X265AMD_OK && one_launch) {
+            rc = tq_roundtrip_diag_yuv(&ty, dy, &tu, dc, stream);  // luma and both chroma planes of every frame at once
+        } else {
+            if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&ty, dy, stream);
+            if (rc == X265AMD_OK) rc = tq_roundtrip_diag(&tu, dc, stream);
+            if (rc == X265AMD_OK && !both) rc = tq_roundtrip_diag(&tv, dc, stream);
+        }
         if (rc != X265AMD_OK) return rc;
     }
     return X265AMD_OK;

@@ -43,5 +43,10 @@ bool tq_takes_mfma(const x265amd_tq_desc *desc);
 // x265amd_tq_roundtrip restricted to the tile units of an anti-diagonal's CUs where the matrix-core kernel runs
 // (the whole plane otherwise: the result is the same, see intra_kernels.hip)
 int tq_roundtrip_diag(const x265amd_tq_desc *desc, const TqDiag &diag, hipStream_t stream);
+// the luma and the chroma launch of one anti-diagonal step as ONE launch (both descriptors on the matrix-core path,
+// chroma TU = luma TU / 2, no vectors; X265AMD_ERR_ARG otherwise: the caller then launches them one by one)
+int tq_roundtrip_diag_yuv(const x265amd_tq_desc *luma, const TqDiag &dl, const x265amd_tq_desc *chroma, const TqDiag &dc,
+                          hipStream_t stream);
+int launch_tq_mfma_diag_yuv(const TqParams &py, const TqParams &pc, hipStream_t stream);
 
 }  // namespace x265amd

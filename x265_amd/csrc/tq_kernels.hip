@@ -396,8 +396,10 @@ static int g_tq_path = 0;
 static unsigned long long *g_tq_trace = nullptr;
 static int g_tq_trace_waves = 0;
 
-template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_t stream, bool coef_in = false, const TqDiag *diag = nullptr)
+// validation + the kernels' parameter block; `empty`: nothing to launch (nframes = 0)
+template <int MODE> static int tq_build(const x265amd_tq_desc *desc, bool coef_in, const TqDiag *diag, TqParams &p, bool &empty)
 {
+    empty = false;
     if (!initialised()) return X265AMD_ERR_NOT_INIT;
     if (!desc) return X265AMD_ERR_ARG;
     const x265amd_tq_desc &d = *desc;
@@ -424,9 +426,11 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     if ((int64_t)d.height * d.level_stride > 0x1fffffff || (int64_t)d.height * d.src_stride > 0x3fffffff ||
         (int64_t)d.height * d.rec_stride > 0x3fffffff || (int64_t)d.height * d.pred_stride > 0x3fffffff)
         return X265AMD_ERR_ARG;  // 32-bit byte offsets inside a plane, all below the out-of-range sentinel of tq_mfma.hip
-    if (d.nframes == 0) return X265AMD_OK;
+    if (d.nframes == 0) {
+        empty = true;
+        return X265AMD_OK;
+    }
 
-    TqParams p;
     p.d = d;
     p.tiles_x = (d.width + 31) / 32;
     p.tiles_y = (d.height + 31) / 32;
@@ -456,6 +460,17 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
         p.dq_rnd = 0;
         p.dq_shift = 0;
     }
+    return X265AMD_OK;
+}
+
+template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_t stream, bool coef_in = false, const TqDiag *diag = nullptr)
+{
+    TqParams p;
+    bool empty;
+    const int st = tq_build<MODE>(desc, coef_in, diag, p, empty);
+    if (st != X265AMD_OK || empty) return st;
+    const x265amd_tq_desc &d = p.d;
+    const int64_t nt = p.ntiles;
     // the matrix-core formulation (tq_mfma.hip) wherever the transform matrix is the same for every TU of the
     // plane and the rows split into 16-byte pieces; per-TU DST selection at 4x4 (d_modes), widths that are not a
     // multiple of 16 and the debug switch keep the butterfly kernel
@@ -479,6 +494,18 @@ bool tq_takes_mfma(const x265amd_tq_desc *desc)
     const bool small = d.height < kLim && d.level_stride < kLim && d.pred_stride < kLim && d.src_stride < kLim &&
                        d.rec_stride < kLim;
     return g_tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0 && small;
+}
+
+int tq_roundtrip_diag_yuv(const x265amd_tq_desc *luma, const TqDiag &dl, const x265amd_tq_desc *chroma, const TqDiag &dc,
+                          hipStream_t stream)
+{
+    TqParams py, pc;
+    bool e1, e2;
+    int st = tq_build<TQ_BOTH>(luma, false, &dl, py, e1);
+    if (st == X265AMD_OK) st = tq_build<TQ_BOTH>(chroma, false, &dc, pc, e2);
+    if (st != X265AMD_OK) return st;
+    if (e1 || e2 || !tq_takes_mfma(luma) || !tq_takes_mfma(chroma)) return X265AMD_ERR_ARG;
+    return launch_tq_mfma_diag_yuv(py, pc, stream);
 }
 
 int tq_roundtrip_diag(const x265amd_tq_desc *desc, const TqDiag &diag, hipStream_t stream)

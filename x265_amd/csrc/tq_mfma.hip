@@ -141,8 +141,9 @@ struct TilePos {  // wave-uniform
     int f, ty, txg;
 };
 
+// the kernel's body; bx / by / gdx = the workgroup's place in the grid (blockIdx.x, blockIdx.y, gridDim.x of a plain launch)
 template <int N, int MODE, bool MV>
-__global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
+__device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, const int by, const int gdx)
 {
     constexpr int L2 = (N == 4) ? 2 : (N == 8) ? 3 : (N == 16) ? 4 : 5;
     constexpr int FI = L2 - 2;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     }
     auto trace_end = [&]() {
         if (p.d_trace && lane == 0) {
-            unsigned long long *rec = p.d_trace + ((size_t)blockIdx.x * 4 + wave) * 4;
+            unsigned long long *rec = p.d_trace + ((size_t)bx * 4 + wave) * 4;
             const unsigned hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
             const unsigned xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // HW_REG_XCC_ID
             rec[0] = t_wall0;
@@ -172,14 +173,14 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
 
     const int ntxg = (p.tiles_x + 3) >> 2;
     const int nunits = ntxg * p.tiles_y * d.nframes;
-    const int per = (nunits + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int per = (nunits + gdx - 1) / gdx;
     // diagonal mode (p.diag_count > 0): ONE unit per workgroup, the one that holds CU (diag_d - 2 cuy, cuy) of frame
-    // blockIdx.y, cuy = diag_lo + blockIdx.x (the launcher sizes the grid; units that two CUs share are done twice,
+    // by, cuy = diag_lo + bx (the launcher sizes the grid; units that two CUs share are done twice,
     // to the same values)
     const bool diag = p.diag_count > 0;
     // ... and of that unit only the tile that holds the CU: the other three waves of the workgroup load nothing and skip
-    const int only_tx = diag ? __builtin_amdgcn_readfirstlane(((p.diag_d - 2 * (p.diag_lo + (int)blockIdx.x)) << p.diag_cu_log2) >> 5) : -1;
-    const int u_beg = diag ? 0 : blockIdx.x * per, u_end = diag ? 1 : min(u_beg + per, nunits);
+    const int only_tx = diag ? __builtin_amdgcn_readfirstlane(((p.diag_d - 2 * (p.diag_lo + bx)) << p.diag_cu_log2) >> 5) : -1;
+    const int u_beg = diag ? 0 : bx * per, u_end = diag ? 1 : min(u_beg + per, nunits);
     if (u_beg >= u_end) return;  // block-uniform; no barriers in this kernel
 
     // constant operands of this lane
@@ -312,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
         pos0.ty = rem / ntxg;
         pos0.txg = rem - pos0.ty * ntxg;
         if (diag) {
-            const int cuy = p.diag_lo + (int)blockIdx.x, cux = p.diag_d - 2 * cuy;
-            pos0.f = p.diag_fgroup ? ((int)blockIdx.y / p.diag_fgroup) * p.diag_fmul + (int)blockIdx.y % p.diag_fgroup : (int)blockIdx.y;
+            const int cuy = p.diag_lo + bx, cux = p.diag_d - 2 * cuy;
+            pos0.f = p.diag_fgroup ? (by / p.diag_fgroup) * p.diag_fmul + by % p.diag_fgroup : by;
             pos0.ty = (cuy << p.diag_cu_log2) >> 5;
             pos0.txg = ((cux << p.diag_cu_log2) >> 5) >> 2;
         }
@@ -441,8 +442,8 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
                 }
                 // one lane per TU column writes; TU rows below the picture are past the end of the resource
                 const __amdgpu_buffer_rsrc_t sum_rs = __builtin_amdgcn_make_buffer_rsrc(
-                    d.d_abs_sum + (p.diag_fgroup ? (int64_t)((int)blockIdx.y / p.diag_fgroup) * d.abs_sum_frame_stride +
-                                                       (int64_t)((int)blockIdx.y % p.diag_fgroup) * p.diag_sum_pair
+                    d.d_abs_sum + (p.diag_fgroup ? (int64_t)(by / p.diag_fgroup) * d.abs_sum_frame_stride +
+                                                       (int64_t)(by % p.diag_fgroup) * p.diag_sum_pair
                                                  : (int64_t)f * d.abs_sum_frame_stride),
                     0, (uint32_t)((d.height >> L2) * (d.width >> L2)) * 4u, kRsrcFlags);
                 const bool writer = (N == 32 ? lane == 63 : (c & (N - 1)) == 0 && (N == 4 || h == 0)) && col_ok;
@@ -533,6 +534,24 @@ __global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
     trace_end();
 }
 
+template <int N, int MODE, bool MV>
+__global__ __launch_bounds__(256, 2) void tq_mfma_kernel(const TqParams p)
+{
+    tq_mfma_body<N, MODE, MV>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+}
+
+// One anti-diagonal step of x265amd_intra_encode_frame(s) in ONE launch: blockIdx.z = 0 the luma plane (TU = N), 1 the
+// chroma planes (TU = N / 2); the grid's y extent is the larger of the two plane counts.
+template <int N>
+__global__ __launch_bounds__(256, 2) void tq_mfma_diag_yuv_kernel(const TqParams py, const TqParams pc, const int ny_luma, const int ny_chroma)
+{
+    if (blockIdx.z == 0) {
+        if ((int)blockIdx.y < ny_luma) tq_mfma_body<N, TQ_BOTH, false>(py, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+    } else {
+        if ((int)blockIdx.y < ny_chroma) tq_mfma_body<N / 2, TQ_BOTH, false>(pc, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x);
+    }
+}
+
 template <int MODE, bool MV> static void launch_n(int tu, dim3 grid, hipStream_t stream, const TqParams &p)
 {
     switch (tu) {
@@ -585,6 +604,40 @@ int launch_tq_mfma(int mode, const TqParams &p_in, hipStream_t stream)
         launch_mv<TQ_INV>(grid, stream, p);
     else
         launch_mv<TQ_BOTH>(grid, stream, p);
+    return hip_status(hipGetLastError());
+}
+
+// validation of a diagonal launch's parameters; ny = planes in the grid's y
+static int diag_check(const TqParams &p, int &ny)
+{
+    const int cu = 1 << p.diag_cu_log2;
+    const int hi = p.diag_lo + p.diag_count - 1;
+    if (p.diag_count <= 0 || p.diag_cu_log2 < 3 || p.diag_cu_log2 > 5 || p.diag_lo < 0 || (hi + 1) * cu > p.d.height || p.diag_d - 2 * hi < 0 ||
+        (p.diag_d - 2 * p.diag_lo + 1) * cu > p.d.width || p.d.nframes > 65535)
+        return X265AMD_ERR_ARG;
+    if (p.diag_fgroup < 0 || (p.diag_fgroup > 0 && (p.diag_fmul < p.diag_fgroup || (int64_t)p.d.nframes * p.diag_fgroup > 65535)))
+        return X265AMD_ERR_ARG;
+    ny = p.diag_fgroup ? p.d.nframes * p.diag_fgroup : p.d.nframes;
+    return X265AMD_OK;
+}
+
+int launch_tq_mfma_diag_yuv(const TqParams &py_in, const TqParams &pc_in, hipStream_t stream)
+{
+    TqParams py = py_in, pc = pc_in;
+    int nyl = 0, nyc = 0;
+    int st = diag_check(py, nyl);
+    if (st == X265AMD_OK) st = diag_check(pc, nyc);
+    if (st != X265AMD_OK) return st;
+    // the same CUs in both: a chroma CU is half the luma CU
+    if (py.diag_count != pc.diag_count || py.diag_d != pc.diag_d || py.diag_lo != pc.diag_lo || py.diag_cu_log2 != pc.diag_cu_log2 + 1 ||
+        py.d.tu != 2 * pc.d.tu || (py.d.tu != 32 && py.d.tu != 16) || py.d.d_mv || pc.d.d_mv)
+        return X265AMD_ERR_ARG;
+    py.d_trace = pc.d_trace = nullptr;
+    const dim3 grid((unsigned)py.diag_count, (unsigned)(nyl > nyc ? nyl : nyc), 2);
+    if (py.d.tu == 32)
+        hipLaunchKernelGGL(tq_mfma_diag_yuv_kernel<32>, grid, dim3(256), 0, stream, py, pc, nyl, nyc);
+    else
+        hipLaunchKernelGGL(tq_mfma_diag_yuv_kernel<16>, grid, dim3(256), 0, stream, py, pc, nyl, nyc);
     return hip_status(hipGetLastError());
 }
 
