@@ -17,17 +17,17 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _both(gpu, cur, ref, R):
+def _both(gpu, cur, ref, R, ctu=64):
     """(static-scratch result, workspace result, device bytes in use before / after the static call)"""
     f = cur.shape[0] if cur.dim() == 3 else 1
     nrefs = ref.shape[1] if ref.dim() == 4 else 1
     h, w = cur.shape[-2:]
-    nctu = (h // 64) * (w // 64)
-    want = gpu.me_fullsearch(cur, ref, 64, R, method="sea").clone()
+    nctu = (h // ctu) * (w // ctu)
+    want = gpu.me_fullsearch(cur, ref, ctu, R, method="sea").clone()
     out = torch.full((f, nrefs, nctu, 2), -1, dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
-    got = gpu.me_fullsearch(cur, ref, 64, R, out=out, method="sea_static")
+    got = gpu.me_fullsearch(cur, ref, ctu, R, out=out, method="sea_static")
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     return got, want, free0, free1
@@ -49,6 +49,10 @@ def test_sea_static_matches_workspace_entry_point_twice(gpu):
     refs = torch.stack([fr[1:3], fr[0:2]], dim=1).contiguous()     # [2][2][H][W]
     got2, want2, f0, f1 = _both(gpu, cur, refs, 33)
     assert torch.equal(got2, want2)
+    assert f0 == f1
+    # a 32x32 block grid on the same scratch (other kernels' instantiations, four times the blocks)
+    got4, want4, f0, f1 = _both(gpu, cur, refs, 33, ctu=32)
+    assert torch.equal(got4, want4)
     assert f0 == f1
     # and the first job again: the small job's leftovers do not matter either
     got3, want3, _, _ = _both(gpu, dev(big[1]), dev(big[0]), 64)
