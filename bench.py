@@ -275,20 +275,22 @@ def cpu_baseline(frames_np, ctu, rng, nrefs, tu, qp, gpu_mv, gpu_level, gpu_rec,
     h, w = frames_np.shape[1:]
     nctu = (h // ctu) * (w // ctu)
     cur, prev = frames_np[nrefs], frames_np[nrefs - 1]
-    # size the sample for ~10-30 core-seconds of CPU work: one CTU costs ~ (2R+1)^2 * ctu^2 / 0.7e9 s per core
-    per_ctu = (2 * rng + 1) ** 2 * ctu * ctu / 0.7e9
-    count = int(max(threads * 2, min(nctu, 30.0 / per_ctu)))
-    step = max(nctu // count, 1)
+    # one core first, on a few CTUs spread over the frame: it calibrates the sample (the compiled reference's
+    # xSad64xN vectorises to ~10 ms per CTU on the box's cores, ~95 ms here)
+    n1 = max(2, min(nctu, 16))
+    step1 = max(nctu // n1, 1)
     t0 = time.perf_counter()
-    mv = me_lib.me_fullsearch(cur, prev, ctu, rng, first=step // 2, step=step, count=count, nthreads=threads)
-    t_me = time.perf_counter() - t0
-    idx = np.arange(step // 2, nctu, step)[:count]
-    parity = bool((mv[idx] == gpu_mv[idx]).all())
-    # one core: a smaller sample of the same CTUs
-    n1 = max(2, min(len(idx), int(3.0 / per_ctu)))
-    t0 = time.perf_counter()
-    me_lib.me_fullsearch(cur, prev, ctu, rng, first=step // 2, step=step, count=n1, nthreads=1)
+    me_lib.me_fullsearch(cur, prev, ctu, rng, first=step1 // 2, step=step1, count=n1, nthreads=1)
     t_me1 = (time.perf_counter() - t0) / n1
+    # all cores: ~15 core-seconds of CTUs, the whole frame if that is less
+    count = int(max(threads * 2, min(nctu, 15.0 / t_me1)))
+    step = max(nctu // count, 1)
+    first = 0 if count == nctu else step // 2
+    t0 = time.perf_counter()
+    mv = me_lib.me_fullsearch(cur, prev, ctu, rng, first=first, step=step, count=count, nthreads=threads)
+    t_me = time.perf_counter() - t0
+    idx = np.arange(first, nctu, step)[:count]
+    parity = bool((mv[idx] == gpu_mv[idx]).all())
 
     # TQ on the whole frame with the GPU's vectors (identical to the CPU's where sampled).  The reference's
     # xSubDct / xQuant / xDeQuant / xIDctAdd are single-threaded code: all cores = one CTU row of TUs per task.
@@ -327,8 +329,8 @@ def cpu_baseline(frames_np, ctu, rng, nrefs, tu, qp, gpu_mv, gpu_level, gpu_rec,
         "cores": threads,
         "kind": kind,
         "one_core_value": round(nominal_px_per_frame / sec_per_frame_1 / 1e6, 4),
-        "sample": f"ME: {len(idx)} of {nctu} CTUs of one frame (every {step}th) in {t_me:.2f} s wall on {threads} threads "
-                  f"({n1} of them on one core: {t_me1 * 1e3:.1f} ms per CTU), scaled to the frame "
+        "sample": f"ME: {len(idx)} of {nctu} CTUs of one frame ({'all' if step == 1 else f'every {step}th'}) in {t_me:.2f} s wall "
+                  f"on {threads} threads ({n1} CTUs on one core: {t_me1 * 1e3:.1f} ms per CTU), scaled to the frame "
                   f"({'oracle/_ref xSadN loop' if kind == 'reference' else 'oracle port'}); TQ fwd+inv: one whole frame in "
                   f"{t_tq:.3f} s on {threads} threads, {t_tq1:.3f} s on one core ({tq_how})",
         "parity_with_gpu_on_sample": parity,
