@@ -285,6 +285,15 @@ class IntraEncoder {
     // pointers are skipped.
     void fetch(uint8_t *rec, int16_t *level, uint8_t *mode_y, uint8_t *mode_c, uint32_t *abs_sum = nullptr, int n = 1)
     {
+        fetch_async(rec, level, mode_y, mode_c, abs_sum, n);
+        wait();
+    }
+
+    // The same copies queued behind the encode on the encoder's stream, without waiting: with page-locked destinations
+    // (PinnedBuffer) the call returns at once and the host is free until wait() -- e.g. to write the pictures of the
+    // batch before on its threads while this one is on the GPU (host/encode_i.cpp).
+    void fetch_async(uint8_t *rec, int16_t *level, uint8_t *mode_y, uint8_t *mode_c, uint32_t *abs_sum = nullptr, int n = 1)
+    {
         if (n < 1 || n > batch_) throw Error(X265AMD_ERR_ARG, "IntraEncoder::fetch: more frames than the batch holds");
         const size_t nb = (size_t)batch_;
         if (rec) check(x265amd_memcpy_d2h(rec, rec_->as(), fsz_ * n, stream_), "x265amd_memcpy_d2h");
@@ -294,8 +303,13 @@ class IntraEncoder {
         if (abs_sum)
             for (int pl = 0; pl < 3; pl++)
                 check(x265amd_memcpy_d2h(abs_sum + (size_t)pl * n * ncu_, sum_->as(4 * ncu_ * nb * pl), 4 * ncu_ * n, stream_), "x265amd_memcpy_d2h");
-        check(x265amd_stream_sync(stream_), "x265amd_stream_sync");
     }
+    void wait() { check(x265amd_stream_sync(stream_), "x265amd_stream_sync"); }
+
+    // the number the next picture written will carry (pictures of several encoders that take turns on one sequence:
+    // the caller keeps the count)
+    int poc() const { return poc_; }
+    void set_poc(int poc) { poc_ = poc; }
 
     // The picture's bitstream from what fetch() brought back (Stage 4 of the reference's loop plus its headers and
     // slice end: x265amd_intra_write_picture, host code).  Pictures are numbered in the order they are written:

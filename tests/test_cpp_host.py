@@ -147,6 +147,13 @@ def test_cpp_host_intra_encoder_reconstruction_md5(gpu, oracle, tmp_path):
     for ext in (".rec", ".lvl", ".modes", ".bit"):
         with open(prefix + ext, "rb") as fa, open(prefix2 + ext, "rb") as fb:
             assert fa.read() == fb.read(), ext
+    # bitstream only (dumps = 0: the reconstruction stays on the GPU): the same stream
+    prefix3 = str(tmp_path / "out_bits")
+    r = subprocess.run([exe, str(src), str(w), str(h), str(nf), str(cu), str(qp), prefix3, "2", "2", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert not os.path.exists(prefix3 + ".rec")
+    with open(prefix + ".bit", "rb") as fa, open(prefix3 + ".bit", "rb") as fb:
+        assert fa.read() == fb.read()
     # geometry the reference rejects (src/params.cpp:73-77) comes back as an error, not a crash
     r = subprocess.run([exe, str(src), "100", "64", "1", "16", "30", prefix], capture_output=True, text=True, timeout=60)
     assert r.returncode == 3 and "IntraEncoder" in r.stderr
