@@ -36,6 +36,15 @@ void x265amd_debug_sea_shape(int lds_pad_bytes, int waves);
  * two are independent formulations of the same arithmetic and must agree bit for bit */
 void x265amd_debug_tq_path(int path);
 
+/* x265amd_intra_encode_frame(s): 1 (default) = an anti-diagonal step is ONE launch, the transform stage of a CU runs at
+ * the end of its prediction workgroup (intra_wave_tq_kernel); 0 = prediction kernel and transform stage as two
+ * launches.  Same output either way (A/B timing, parity tests). */
+void x265amd_debug_intra_fused(int on);
+/* .. threads per workgroup of that kernel: 1024 (16 waves, one workgroup to a compute unit: the shape for a step with
+ * few CUs), 512 (8 waves, two to a compute unit) or 256 (4 waves, four to a compute unit): a batch's steps; 0 (default)
+ * = by the number of CUs in the step */
+void x265amd_debug_intra_threads(int threads);
+
 /* Where and when the waves of the matrix-core TQ kernel ran: with a non-null device buffer of nwaves x 4
  * 64-bit words (nwaves >= 4 x the workgroups of the launch, else nothing is recorded; zeroed by the caller) every wave of the following
  * launches of that kernel leaves {start, end (100 MHz wall clock), shader clocks spent,

@@ -797,6 +797,40 @@ def test_intra_frames_batch_equals_single_frames(gpu, oracle, w, h, cu, qp, n):
             np.testing.assert_array_equal(host(o["level"][fr]), lv)
 
 
+def test_intra_step_as_one_launch_equals_two_launches(gpu, oracle):
+    """The transform stage at the end of the prediction workgroups (intra_wave_tq_kernel, the default) against the
+    prediction kernel + transform launch pair (x265amd_debug_intra_fused(0)), and the 16-wave against the 8-wave shape
+    of the kernel (x265amd_debug_intra_threads): every output equal, for a single frame (plane layout: U and V as two
+    planes of one launch), a batch of frame buffers (plane pairs), CU 32 and CU 16."""
+    from x265_amd import synth, api
+    lib = api._lib()
+    rng = np.random.default_rng(77)
+    try:
+        for (w, h, cu, qp, n) in ((416, 224, 32, 27, 3), (416, 240, 16, 32, 2), (1920, 1088, 32, 32, 2)):
+            fsz = w * h * 3 // 2
+            yuv = np.stack([synth.make_intra_probe(w, h, 1)[0]] + [rng.integers(0, 256, fsz, dtype=np.uint8) for _ in range(n - 1)])
+            outs = []
+            for fused, threads in ((1, 0), (0, 0), (1, 256), (1, 512), (1, 1024), (0, 256), (0, 512)):
+                lib.x265amd_debug_intra_fused(fused)
+                lib.x265amd_debug_intra_threads(threads)  # 0: by the step's size; else the 4- / 8- / 16-wave shape of the kernel
+                o = gpu.intra_encode_frames(dev(yuv), w, h, cu, qp)
+                y, u, v = _planes_of(yuv[n - 1], w, h)
+                s = gpu.intra_encode_frame(dev(y), dev(u), dev(v), cu, qp)
+                outs.append(({k: host(t) for k, t in o.items()}, {k: host(t) for k, t in s.items()}))
+            for other in outs[1:]:
+                for a, b in zip(outs[0], other):
+                    assert a.keys() == b.keys()
+                    for k in a:
+                        np.testing.assert_array_equal(a[k], b[k], f"{w}x{h} cu {cu}: {k}")
+            if w * h <= 416 * 240:
+                orec, my, mc, lv = oracle.intra_encode_frame(yuv[1], w, h, cu, qp, want_levels=True)
+                np.testing.assert_array_equal(outs[0][0]["rec"][1], orec)
+                np.testing.assert_array_equal(outs[0][0]["level"][1], lv)
+    finally:
+        lib.x265amd_debug_intra_fused(1)
+        lib.x265amd_debug_intra_threads(0)
+
+
 def test_closed_loop_gop_with_intra_first_picture(gpu, oracle):
     """A whole GOP segment on the GPU: the I picture through the intra path (ClosedLoopGop.encode_i, the two segments
     as its batch), the P pictures searched against and predicted from ITS reconstruction.  CPU chain: the oracle's

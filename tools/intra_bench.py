@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One intra frame on the GPU (x265amd_intra_encode_frame): time per frame launched eagerly and replayed from a
 captured graph (the frame is 3 launches per anti-diagonal of CUs: launch-bound), beside the CPU reference /
-restatement on this box's host.  Run on the GPU box:  python tools/intra_bench.py"""
+restatement on this box's host.  Run on the GPU box:  python tools/intra_bench.py [--two-launches]
+(--two-launches: the transform stage of a step as a launch of its own, x265amd_debug_intra_fused(0), for comparison)"""
 import os
 import sys
 import time
@@ -22,6 +23,13 @@ def planes(yuv, w, h):
 def main():
     gpu.init(0)
     orc = pyoracle.Oracle()
+    if "--two-launches" in sys.argv[1:]:
+        api._lib().x265amd_debug_intra_fused(0)
+        print("prediction kernel and transform stage as two launches per step")
+    for a in sys.argv[1:]:
+        if a.startswith("--threads="):
+            api._lib().x265amd_debug_intra_threads(int(a.split("=")[1]))
+            print(f"prediction kernel forced to {a.split('=')[1]} threads per workgroup")
     for (w, h, cu, qp) in ((416, 240, 16, 32), (1920, 1088, 32, 32), (3840, 2176, 32, 32)):
         yuv = synth.make_intra_probe(w, h, 1)[0]
         chroma = torch.from_numpy(np.ascontiguousarray(yuv[w * h:]).reshape(2, h // 2, w // 2)).cuda()

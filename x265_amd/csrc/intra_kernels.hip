@@ -14,6 +14,7 @@
 // residual stage (src/encode.cpp:867).
 #include "common.h"
 #include "tq_common.h"
+#include "tq_mfma_body.h"
 
 namespace x265amd {
 
@@ -342,12 +343,15 @@ __device__ __forceinline__ int intra_ref_sample(const uint8_t *rec, int stride, 
 }
 
 // 16 waves per CU here: an anti-diagonal has few CUs (34 at 1080p with CU 32), so the launch is as long as one
-// CU takes, and the 35 + 5 candidate modes of a CU are what there is to spread
-constexpr int kWaveThreads = 1024;
-template <int N>
-__global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWave w)
+// CU takes, and the 35 + 5 candidate modes of a CU are what there is to spread.  A batch of frames brings more CUs per
+// step than the chip has compute units: then 8 or 4 waves per CU, two or four workgroups to a compute unit (the
+// registers allow 16 waves there either way), so that one workgroup's serial stretches -- sample loads, the argmin
+// threads, the transform stage's three waves -- run beside the others' SADs.
+// the body of the prediction kernel of a step; false: this workgroup has no CU (block-uniform)
+template <int N, int NT>
+__device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
 {
-    constexpr int NT = kWaveThreads, NWAVES = NT / 64;
+    constexpr int NWAVES = NT / 64;
     constexpr int L2 = N == 16 ? 4 : 5;
     constexpr int NC = N / 2, L2C = L2 - 1;
     constexpr int NPIX = N * N, PER = NPIX / 64;
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cuy = w.cy_lo + blockIdx.x, cux = w.d - 2 * cuy;
-    if (cux < 0 || cux >= w.ncx || cuy >= w.ncy) return;  // block-uniform (the host sizes the grid to fit)
+    if (cux < 0 || cux >= w.ncx || cuy >= w.ncy) return false;  // block-uniform (the host sizes the grid to fit)
     const int x0 = cux * N, y0 = cuy * N, cu = cuy * w.ncx + cux;
     const bool bL = cux > 0, bT = cuy > 0, bTR = bT && cux + 1 < w.ncx;
 
@@ -393,12 +397,22 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
     const int left_mode = (tid == NT - 1 && bL) ? f.d_mode_y[cu - 1] : 1;
     // the source once more, a pixel per thread: laid out in LDS by rows and by columns, the quads of four pixels that
     // intra_luma_sads_quads compares against are aligned dwords there whatever the plane's stride and address
-    const int tpix = tid < NPIX ? f.d_src_y[(int64_t)(y0 + (tid >> L2)) * f.stride_y + x0 + (tid & (N - 1))] : 0;
+    constexpr int TP = (NPIX + NT - 1) / NT;
+    int tpix[TP];
+#pragma unroll
+    for (int t = 0; t < TP; t++) {
+        const int i = tid + NT * t;
+        tpix[t] = i < NPIX ? f.d_src_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))] : 0;
+    }
 
     // ---- reference samples: luma, and its smoothed copy; U and V ----
-    if (tid < NPIX) {
-        s_srcq[0][tid >> L2][tid & (N - 1)] = (uint8_t)tpix;
-        s_srcq[1][tid & (N - 1)][tid >> L2] = (uint8_t)tpix;
+#pragma unroll
+    for (int t = 0; t < TP; t++) {
+        const int i = tid + NT * t;
+        if (i < NPIX) {
+            s_srcq[0][i >> L2][i & (N - 1)] = (uint8_t)tpix[t];
+            s_srcq[1][i & (N - 1)][i >> L2] = (uint8_t)tpix[t];
+        }
     }
     if (tid <= 4 * N) s_ref[0][tid] = (uint8_t)intra_ref_sample(f.d_rec_y, f.stride_y, x0, y0, N, tid, bL, bT, bTR);
     for (int i = tid; i < 2 * (4 * NC + 1); i += NT) {
@@ -513,6 +527,32 @@ __global__ __launch_bounds__(kWaveThreads) void intra_wave_kernel(const IntraWav
         const int64_t o = (int64_t)(y0 / 2 + (j >> L2C)) * f.stride_c + x0 / 2 + (j & (NC - 1));
         (pl ? f.d_pred_v : f.d_pred_u)[o] = (uint8_t)intra_pixel<NC, false>(s_refc[pl], bmc, j >> L2C, j & (NC - 1), s_dcc[pl]);
     }
+    return true;
+}
+
+template <int N, int NT>
+__global__ __launch_bounds__(NT, 1024 / NT) void intra_wave_kernel(const IntraWave w)
+{
+    intra_wave_body<N, NT>(w);
+}
+
+// A whole anti-diagonal step in one launch: the prediction of the workgroup's CU as above, then its transform stage
+// (forward + inverse of the 32x32 tiles that hold the CU's luma and chroma blocks: tq_mfma_body in diagonal mode,
+// exactly what tq_mfma_diag_yuv_kernel runs as a launch of its own) on three of the workgroup's waves -- luma, U, V.
+// The predictions they read were stored by this workgroup: visible after the barrier (one compute unit, one L1).
+// py / pc: the transform stage's parameters for the luma plane and for the chroma planes; the workgroup's frame g
+// takes chroma planes by = g * cby_mul and g * cby_mul + cby_add of pc (see intra_encode for the three layouts).
+template <int N, int NT>
+__global__ __launch_bounds__(NT, 1024 / NT) void intra_wave_tq_kernel(const IntraWave w, const TqParams py, const TqParams pc, const int cby_mul,
+                                                                      const int cby_add)
+{
+    if (!intra_wave_body<N, NT>(w)) return;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (wave == 0)
+        tq_mfma_body<N, TQ_BOTH, false>(py, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, -1);
+    else if (wave <= 2)
+        tq_mfma_body<N / 2, TQ_BOTH, false>(pc, (int)blockIdx.x, (int)blockIdx.y * cby_mul + (wave == 2 ? cby_add : 0), (int)gridDim.x, -1);
 }
 
 }  // namespace x265amd
@@ -557,12 +597,24 @@ static int intra_frame_check(const x265amd_intra_frame *f)
     return X265AMD_OK;
 }
 
+// x265amd_debug_intra_fused (include/x265_amd_debug.h): 0 keeps the transform stage a launch of its own (A/B runs)
+static int g_intra_fused = 1;
+// x265amd_debug_intra_threads: threads per workgroup of the prediction kernel, 256, 512 or 1024 (0 = by the step's size)
+static int g_intra_threads = 0;
+
 struct IntraBatch {
     int nframes;
     int64_t fs_y, fs_c, fs_cu;
 };
 
-static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st, const IntraBatch &b = IntraBatch{1, 0, 0, 0})
+// the transform stage that rides at the end of the prediction kernel (intra_wave_tq_kernel), or none
+struct IntraTq {
+    const TqParams *py = nullptr, *pc = nullptr;
+    int cby_mul = 0, cby_add = 0;
+};
+
+static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st, const IntraBatch &b = IntraBatch{1, 0, 0, 0},
+                             const IntraTq &tq = IntraTq{})
 {
     IntraWave w;
     w.f = *f;
@@ -576,13 +628,34 @@ static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st
     const int hi = d / 2 < w.ncy - 1 ? d / 2 : w.ncy - 1;
     if (hi < lo) return X265AMD_OK;
     w.cy_lo = lo;
-    const dim3 grid((unsigned)(hi - lo + 1), (unsigned)b.nframes), block(kWaveThreads);
-    if (f->cu == 16)
-        hipLaunchKernelGGL(intra_wave_kernel<16>, grid, block, 0, st, w);
-    else
-        hipLaunchKernelGGL(intra_wave_kernel<32>, grid, block, 0, st, w);
+    // more CUs in the step than the chip has compute units: the 8-wave shape, two workgroups to a compute unit; more
+    // than twice as many: 4 waves, four to a compute unit
+    const int64_t nwg = (int64_t)(hi - lo + 1) * b.nframes;
+    const int threads = g_intra_threads ? g_intra_threads : nwg > 2 * cu_count() ? 256 : nwg > cu_count() ? 512 : 1024;
+    const dim3 grid((unsigned)(hi - lo + 1), (unsigned)b.nframes), block((unsigned)threads);
+#define X265AMD_INTRA_SHAPES(KERNEL, NN, ...)                                                              \
+    switch (threads) {                                                                                     \
+    case 256: hipLaunchKernelGGL((KERNEL<NN, 256>), grid, block, 0, st, __VA_ARGS__); break;             \
+    case 512: hipLaunchKernelGGL((KERNEL<NN, 512>), grid, block, 0, st, __VA_ARGS__); break;             \
+    default: hipLaunchKernelGGL((KERNEL<NN, 1024>), grid, block, 0, st, __VA_ARGS__); break;             \
+    }
+    if (tq.py) {
+        // what the kernel assumes of the stage's parameters: this diagonal, these CUs, a grid that matches
+        if (tq.py->diag_d != d || tq.py->diag_lo != lo || tq.py->diag_count != hi - lo + 1 || (1 << tq.py->diag_cu_log2) != f->cu ||
+            tq.py->d.tu != f->cu || f->cu != 32)
+            return X265AMD_ERR_ARG;
+        X265AMD_INTRA_SHAPES(intra_wave_tq_kernel, 32, w, *tq.py, *tq.pc, tq.cby_mul, tq.cby_add)
+    } else if (f->cu == 16) {
+        X265AMD_INTRA_SHAPES(intra_wave_kernel, 16, w)
+    } else {
+        X265AMD_INTRA_SHAPES(intra_wave_kernel, 32, w)
+    }
+#undef X265AMD_INTRA_SHAPES
     return hip_status(hipGetLastError());
 }
+
+extern "C" void x265amd_debug_intra_fused(int on) { g_intra_fused = on; }
+extern "C" void x265amd_debug_intra_threads(int threads) { g_intra_threads = threads == 256 || threads == 512 || threads == 1024 ? threads : 0; }
 
 extern "C" int x265amd_intra_waves(const x265amd_intra_frame *f)
 {
@@ -661,12 +734,33 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
     const int nw = x265amd_intra_waves(f);
     const int ncx = f->width / f->cu, ncy = f->height / f->cu;
     const int l2 = f->cu == 16 ? 4 : 5;
+    // chroma planes of frame g as tq_mfma_body counts them (`by`): U and V of the one frame; planes 2 g and 2 g + 1 of
+    // the pairs; or g among the U planes and nframes + g among the V planes
+    // Only where no two CUs of one anti-diagonal share a 32x32 tile of any plane: the transform stage writes whole
+    // tiles (blocks of later steps come out as garbage until their own step), which is harmless between launches but
+    // not inside one.  The CUs of a tile are on diagonals d0 + i + 2 l, i, l < 32 / block: distinct for blocks of 32
+    // and of 16 (CU 32: luma 32, chroma 16), not for the 8x8 chroma blocks of CU 16 (i = 2, l = 0 meets i = 0, l = 1).
+    const bool fused_ok = one_launch && g_intra_fused && f->cu == 32;
+    IntraTq fused;
+    fused.cby_mul = b.nframes == 1 ? 0 : pair.fgroup ? 2 : 1;
+    fused.cby_add = b.nframes == 1 || pair.fgroup ? 1 : b.nframes;
     for (int d = 0; d < nw; d++) {
-        int rc = intra_wave_launch(f, d, stream, b);
         // the transform stage follows the diagonal: only the tile units that hold its CUs
         const int lo = d - (ncx - 1) > 0 ? (d - (ncx - 1) + 1) / 2 : 0;
         const int hi = d / 2 < ncy - 1 ? d / 2 : ncy - 1;
         const TqDiag dy{hi - lo + 1, d, lo, l2}, dc{hi - lo + 1, d, lo, l2 - 1, pair.fgroup, pair.fmul, pair.sum_pair};
+        if (fused_ok) {
+            // prediction and transform stage of the step as one launch
+            TqParams py, pc;
+            int nyl = 0, nyc = 0;
+            int rc = tq_diag_yuv_params(&ty, dy, &tu, dc, py, pc, nyl, nyc);
+            if (rc == X265AMD_OK && (nyl != b.nframes || nyc != 2 * b.nframes)) rc = X265AMD_ERR_ARG;  // the `by` the kernel forms
+            fused.py = &py, fused.pc = &pc;
+            if (rc == X265AMD_OK) rc = intra_wave_launch(f, d, stream, b, fused);
+            if (rc != X265AMD_OK) return rc;
+            continue;
+        }
+        int rc = intra_wave_launch(f, d, stream, b);
         if (rc == X265AMD_OK && one_launch) {
             rc = tq_roundtrip_diag_yuv(&ty, dy, &tu, dc, stream);  // luma and both chroma planes of every frame at once
         } else {

@@ -48,5 +48,10 @@ int tq_roundtrip_diag(const x265amd_tq_desc *desc, const TqDiag &diag, hipStream
 int tq_roundtrip_diag_yuv(const x265amd_tq_desc *luma, const TqDiag &dl, const x265amd_tq_desc *chroma, const TqDiag &dc,
                           hipStream_t stream);
 int launch_tq_mfma_diag_yuv(const TqParams &py, const TqParams &pc, hipStream_t stream);
+// .. and the same step's kernel parameters without the launch, checked (for a caller whose own kernel runs tq_mfma_body
+// in diagonal mode: intra_wave_tq_kernel); ny_luma / ny_chroma = planes that py / pc address (the `by` range)
+int tq_diag_yuv_params(const x265amd_tq_desc *luma, const TqDiag &dl, const x265amd_tq_desc *chroma, const TqDiag &dc, TqParams &py,
+                       TqParams &pc, int &ny_luma, int &ny_chroma);
+int tq_mfma_diag_yuv_check(TqParams &py, TqParams &pc, int &ny_luma, int &ny_chroma);
 
 }  // namespace x265amd

@@ -496,15 +496,24 @@ bool tq_takes_mfma(const x265amd_tq_desc *desc)
     return g_tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0 && small;
 }
 
-int tq_roundtrip_diag_yuv(const x265amd_tq_desc *luma, const TqDiag &dl, const x265amd_tq_desc *chroma, const TqDiag &dc,
-                          hipStream_t stream)
+int tq_diag_yuv_params(const x265amd_tq_desc *luma, const TqDiag &dl, const x265amd_tq_desc *chroma, const TqDiag &dc, TqParams &py,
+                       TqParams &pc, int &ny_luma, int &ny_chroma)
 {
-    TqParams py, pc;
     bool e1, e2;
     int st = tq_build<TQ_BOTH>(luma, false, &dl, py, e1);
     if (st == X265AMD_OK) st = tq_build<TQ_BOTH>(chroma, false, &dc, pc, e2);
     if (st != X265AMD_OK) return st;
     if (e1 || e2 || !tq_takes_mfma(luma) || !tq_takes_mfma(chroma)) return X265AMD_ERR_ARG;
+    return tq_mfma_diag_yuv_check(py, pc, ny_luma, ny_chroma);
+}
+
+int tq_roundtrip_diag_yuv(const x265amd_tq_desc *luma, const TqDiag &dl, const x265amd_tq_desc *chroma, const TqDiag &dc,
+                          hipStream_t stream)
+{
+    TqParams py, pc;
+    int nyl = 0, nyc = 0;
+    const int st = tq_diag_yuv_params(luma, dl, chroma, dc, py, pc, nyl, nyc);
+    if (st != X265AMD_OK) return st;
     return launch_tq_mfma_diag_yuv(py, pc, stream);
 }
 
