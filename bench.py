@@ -518,13 +518,13 @@ def intra_frames(args, grp, nw, nh, cu, fps, qp):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{nw}x{nh} 4:2:0 (padded {w}x{h}) intra pictures, CU = PU = TU = {cu}, QP{qp}, SLICE_I: "
                                    f"{fps} independent frames per step per GPU through x265amd_intra_encode_frames "
-                                   f"({nsteps} anti-diagonal steps of 2 launches: prediction + decisions, transform stage of the three planes)",
+                                   f"({nsteps} anti-diagonal steps, one launch each: prediction + decisions + transform stage of the three planes)",
                        "name": args.workload, "frames_per_step_per_gpu": fps},
-            "roofline": {"kernel": "the whole step (intra_wave_kernel + tq_mfma_diag_yuv_kernel per anti-diagonal)", "bound": "hbm",
+            "roofline": {"kernel": "the whole step (intra_wave_tq_kernel per anti-diagonal: prediction + transform stage)", "bound": "hbm",
                          "achieved": round(alg / (dev_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": intra_traffic(args.workload, nsteps),
                          "note": "algorithmic bytes = source + reconstruction + Int16 levels; the step is a chain of "
-                                 f"{2 * nsteps} dependent launches of at most {fps} x {min(h // cu, (w // cu + 1) // 2)} workgroups, "
+                                 f"{nsteps} dependent launches of at most {fps} x {min(h // cu, (w // cu + 1) // 2)} workgroups, "
                                  "bound by that chain's latency, not by HBM or the VALU (DESIGN.md 4.6)"},
             "cpu_baseline": cpu,
         }), flush=True)
@@ -537,10 +537,10 @@ def intra_traffic(key, nsteps):
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ks = json.load(f)[key]["kernels"]
-        pred = [k for k in ks if k.startswith("intra_wave_kernel")]
+        pred = [k for k in ks if k.startswith(("intra_wave_kernel", "intra_wave_tq_kernel"))]
         steps = sum(ks[k]["dispatches"] for k in pred) / nsteps
         tot = sum(v["dispatches"] * (v["fetch_bytes_x2"] + v["write_bytes"]) for k, v in ks.items()
-                  if k.startswith(("intra_wave_kernel", "tq_mfma", "tq_kernel")))
+                  if k.startswith(("intra_wave_kernel", "intra_wave_tq_kernel", "tq_mfma", "tq_kernel")))
         return round(tot / steps)
     except Exception:
         return None
