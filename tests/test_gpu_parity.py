@@ -831,6 +831,57 @@ def test_intra_step_as_one_launch_equals_two_launches(gpu, oracle):
         lib.x265amd_debug_intra_threads(0)
 
 
+@pytest.mark.parametrize("cu", [32, 16])
+def test_intra_frames_plane_layouts(gpu, cu):
+    """x265amd_intra_encode_frames through the C-ABI with the planes laid out three ways -- frame buffers Y,U,V (U and V
+    of all frames as plane pairs of one transform launch), plane-major (all Y, all U, all V: one progression), and V
+    before U (no common progression: the chroma planes take a launch each) -- gives the same planes, modes and sums."""
+    import ctypes as C
+    import torch
+    from x265_amd import synth, api
+    w, h, qp, n = 416, 224 if cu == 32 else 240, 30, 3
+    ysz, csz = w * h, w * h // 4
+    fsz, ncus = ysz + 2 * csz, (w // cu) * (h // cu)
+    rng = np.random.default_rng(cu)
+    yuv = np.stack([synth.make_intra_probe(w, h, 1)[0]] + [rng.integers(0, 256, fsz, dtype=np.uint8) for _ in range(n - 1)])
+    want = {k: host(t) for k, t in gpu.intra_encode_frames(dev(yuv), w, h, cu, qp).items()}
+    ys, us, vs = yuv[:, :ysz], yuv[:, ysz:ysz + csz], yuv[:, ysz + csz:]
+    for order in ("yuv", "yvu"):
+        first, second = (us, vs) if order == "yuv" else (vs, us)
+        src = dev(np.concatenate([ys.ravel(), first.ravel(), second.ravel()]))
+        bufs = {k: torch.zeros(n * fsz, dtype=dt, device=src.device) for k, dt in (("rec", torch.uint8), ("pred", torch.uint8), ("level", torch.int16))}
+        small = {k: torch.zeros((n, ncus), dtype=torch.uint8, device=src.device) for k in ("mode_y", "mode_c")}
+        sums = torch.zeros((3, n, ncus), dtype=torch.int32, device=src.device)  # Y, then the chroma planes in memory order
+        costs = torch.zeros((2, n, ncus), dtype=torch.int32, device=src.device)
+        f = api.IntraFrame()
+        f.width, f.height, f.cu, f.qp, f.stride_y, f.stride_c = w, h, cu, qp, w, w // 2
+        off_u = n * ysz + (0 if order == "yuv" else n * csz)
+        off_v = n * ysz + (n * csz if order == "yuv" else 0)
+        for name, t, esz in (("src", src, 1), ("rec", bufs["rec"], 1), ("pred", bufs["pred"], 1), ("level", bufs["level"], 2)):
+            setattr(f, f"d_{name}_y", t.data_ptr())
+            setattr(f, f"d_{name}_u", t.data_ptr() + esz * off_u)
+            setattr(f, f"d_{name}_v", t.data_ptr() + esz * off_v)
+        f.d_mode_y, f.d_mode_c = small["mode_y"].data_ptr(), small["mode_c"].data_ptr()
+        f.d_cost_y, f.d_cost_c = costs[0].data_ptr(), costs[1].data_ptr()
+        f.d_abs_sum_y = sums[0].data_ptr()
+        f.d_abs_sum_u = sums[1 if order == "yuv" else 2].data_ptr()
+        f.d_abs_sum_v = sums[2 if order == "yuv" else 1].data_ptr()
+        api._check(api._lib().x265amd_intra_encode_frames(C.byref(f), n, ysz, csz, ncus, api._stream()), "x265amd_intra_encode_frames")
+        for k in ("rec", "level"):
+            got = host(bufs[k])
+            gy = got[:n * ysz].reshape(n, ysz)
+            gu = got[off_u:off_u + n * csz].reshape(n, csz)
+            gv = got[off_v:off_v + n * csz].reshape(n, csz)
+            np.testing.assert_array_equal(np.concatenate([gy, gu, gv], axis=1), want[k], f"{order}: {k}")
+        for k in ("mode_y", "mode_c"):
+            np.testing.assert_array_equal(host(small[k]), want[k], f"{order}: {k}")
+        np.testing.assert_array_equal(host(costs[0]), want["cost_y"])
+        np.testing.assert_array_equal(host(costs[1]), want["cost_c"])
+        np.testing.assert_array_equal(host(sums[0]), want["abs_sum_y"])
+        np.testing.assert_array_equal(host(sums[1 if order == "yuv" else 2]), want["abs_sum_u"], order)
+        np.testing.assert_array_equal(host(sums[2 if order == "yuv" else 1]), want["abs_sum_v"], order)
+
+
 def test_closed_loop_gop_with_intra_first_picture(gpu, oracle):
     """A whole GOP segment on the GPU: the I picture through the intra path (ClosedLoopGop.encode_i, the two segments
     as its batch), the P pictures searched against and predicted from ITS reconstruction.  CPU chain: the oracle's
