@@ -70,7 +70,7 @@ def main():
               f"({w * h / graph / 1e6:7.1f} Mpix/s); CPU restatement, one core {cpu * 1e3:8.1f} ms/frame; "
               f"identical to it: {np.array_equal(rec, orec) and np.array_equal(ref_rec, orec)}")
         # a batch of independent frames per pass over the anti-diagonals (x265amd_intra_encode_frames)
-        for nb in (4, 8, 16, 32):
+        for nb in (4, 8, 16, 32, 64):
             if nb * w * h * 3 // 2 * 5 > 6e9:
                 continue
             seq = synth.make_intra_probe(w, h, min(nb, 8))
