@@ -158,6 +158,30 @@ const uint8_t kNextLps[64] = {0,  0,  1,  2,  2,  4,  4,  5,  6,  7,  8,  9,  9,
                               18, 18, 19, 19, 21, 21, 22, 22, 23, 24, 24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30,
                               31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63};
 
+// State transitions on (pStateIdx << 1 | valMPS) as the reference tabulates them (src/table.cpp:174-193), built from
+// transIdxLps: an LPS at state 0 flips the MPS, an MPS moves one state up to 62.  renorm[lps >> 3] = g_aucRenormTable
+// (src/table.cpp:263-272): the shift that brings the LPS range to >= 256, except that everything under 8 takes 6.
+struct Transitions {
+    uint8_t lps[128], mps[128], renorm[32];
+    Transitions()
+    {
+        for (int st = 0; st < 128; st++) {
+            const int s = st >> 1, m = st & 1;
+            lps[st] = s == 0 ? (uint8_t)(st ^ 1) : (uint8_t)((kNextLps[s] << 1) | m);
+            mps[st] = s < 62 ? (uint8_t)(st + 2) : (uint8_t)st;
+        }
+        for (int i = 0; i < 32; i++) {
+            int shift = 1;
+            if (i == 0)
+                shift = 6;
+            else
+                while (((8 * i) << shift) < 256) shift++;
+            renorm[i] = (uint8_t)shift;
+        }
+    }
+};
+const Transitions kTrans;
+
 // The arithmetic coder (src/bitstream.cpp:611-775: HM's TEncBinCABAC with its 32-bit low register, 23 spare bits
 // and the deferred carry byte).
 class Cabac {
@@ -178,37 +202,30 @@ public:
     }
     void bin(uint32_t b, int ctx)  // xCabacEncodeBin
     {
-        uint8_t st = state_[ctx];
+        const uint32_t st = state_[ctx];
         const uint32_t lps = kRangeLps[st >> 1][(range_ >> 6) & 3];
         range_ -= lps;
-        if (b != (uint32_t)(st & 1)) {
-            int shift = 1;  // g_aucRenormTable (src/table.cpp:263-272): the shift that brings the LPS range to >= 256,
-            if (lps < 8)    // except that everything under 8 takes 6
-                shift = 6;
-            else
-                while ((lps << shift) < 256) shift++;
+        if (b != (st & 1u)) {
+            const int shift = kTrans.renorm[lps >> 3];
             low_ = (low_ + range_) << shift;
             range_ = lps << shift;
             left_ -= shift;
-            const int s = st >> 1;
-            st = s == 0 ? (uint8_t)(st ^ 1) : (uint8_t)((kNextLps[s] << 1) | (st & 1));
+            state_[ctx] = kTrans.lps[st];
         } else {
-            if ((st >> 1) < 62) st = (uint8_t)(st + 2);
-            if (range_ < 256) {
-                low_ <<= 1;
-                range_ <<= 1;
-                left_--;
-            }
+            state_[ctx] = kTrans.mps[st];
+            if (range_ >= 256) return;  // nothing left `low`: no byte can be due
+            low_ <<= 1;
+            range_ <<= 1;
+            left_--;
         }
-        state_[ctx] = st;
-        drain();
+        if (left_ < 12) drain();
     }
     void bypass(uint32_t b)  // xCabacEncodeBinEP
     {
         low_ <<= 1;
         if (b) low_ += range_;
         left_--;
-        drain();
+        if (left_ < 12) drain();
     }
     void bypass_bits(uint32_t v, int n)  // xCabacEncodeBinsEP: n bins at once, most significant first
     {
@@ -218,11 +235,11 @@ public:
             low_ = (low_ << 8) + range_ * top;
             v -= top << n;
             left_ -= 8;
-            drain();
+            if (left_ < 12) drain();
         }
         low_ = (low_ << n) + range_ * v;
         left_ -= n;
-        drain();
+        if (left_ < 12) drain();
     }
     void terminate(uint32_t b)  // xCabacEncodeTerminatingBit
     {
