@@ -354,11 +354,14 @@ class IntraEncoder {
         s.stride_y = w_, s.stride_c = w_ / 2;
         s.level_y = level, s.level_u = level + ysz_, s.level_v = level + ysz_ + csz_;
         s.mode_y = mode_y, s.mode_c = mode_c;
-        const size_t at = out.size();
-        out.resize(at + x265amd_intra_stream_bound(w_, h_));
+        // The bound is the worst case (7 bytes per sample: 22 MB at 1080p) and a picture is a few hundred KB: the
+        // writer gets an UNINITIALISED block of that size (only the pages it reaches are ever touched; a vector
+        // resized to the bound would zero all of it for every picture) and the bytes it made are appended.
+        const size_t cap = x265amd_intra_stream_bound(w_, h_);
+        std::unique_ptr<uint8_t[]> tmp(new uint8_t[cap]);
         size_t n = 0;
-        check(x265amd_intra_write_picture(&s, out.data() + at, out.size() - at, &n), "x265amd_intra_write_picture");
-        out.resize(at + n);
+        check(x265amd_intra_write_picture(&s, tmp.get(), cap, &n), "x265amd_intra_write_picture");
+        out.insert(out.end(), tmp.get(), tmp.get() + n);
         return n;
     }
 
