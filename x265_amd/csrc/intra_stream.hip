@@ -418,12 +418,17 @@ public:
                 c_.bin(has[gy * side + gx], sig_group0 + (int)(right | below));
             }
             if (has[gy * side + gx]) {
+                // the group's neighbourhood once: bits x .. x + 5 of its four rows and of the two below
+                uint32_t win[6];
+                for (int k = 0; k < 6; k++) win[k] = (m.row[4 * gy + k] >> (4 * gx)) & 0x3fu;
+                const SigGroup sg(gx, gy, n, lg, luma);
                 for (; i >= 0; i--) {
                     const int dx = kDiag4.x[i], dy = kDiag4.y[i];
-                    const int v = g0[dy * stride + dx];
+                    const uint32_t set = (win[dy] >> dx) & 1u;
                     // the first position of a group that was flagged and has shown no level yet is known to hold one
-                    if (i != 0 || s == 0 || cnt) c_.bin(v != 0, sig0 + sig_ctx(m.row, 4 * gx + dx, 4 * gy + dy, n, lg, luma));
-                    if (v) {
+                    if (i != 0 || s == 0 || cnt) c_.bin(set, sig0 + sg.ctx(win, dx, dy));
+                    if (set) {
+                        const int v = g0[dy * stride + dx];
                         mag[cnt++] = v < 0 ? -v : v;
                         signs = (signs << 1) + (v < 0);
                     }
@@ -485,25 +490,43 @@ private:
         }
     }
 
-    // getSigCtxInc (src/encode.cpp:111-190) for N = 8 (blockType 3) and N = 16, 32, on the block's bitmap: the
-    // reference's `x < width - 1`, `y < height - 1` ... guards are the map's empty margins
-    static int sig_ctx(const uint32_t *row, int x, int y, int n, int lg, bool luma)
-    {
-        if (lg == 3) {
-            static const uint8_t map[16] = {0, 1, 2, 3, 4, 5, 6, 3, 8, 6, 6, 7, 9, 9, 7, 7};
-            const int off = luma ? 9 : 6;
-            return x + y == 0 ? off + 10 : off + map[4 * (y >> 1) + (x >> 1)];
+    // getSigCtxInc (src/encode.cpp:111-190) for N = 8 (blockType 3) and N = 16, 32, on the group's window of the
+    // block's bitmap (win[k] bit j = position (4 gx + j, 4 gy + k)): the reference's `x < width - 1`,
+    // `y < height - 1` ... guards are the map's empty margins.  What depends on the group alone is worked out once.
+    struct SigGroup {
+        int lg, off, dc_ctx, far_ctx, near_base, gx2, gy2;
+        bool far, first;
+        SigGroup(int gx, int gy, int n, int lg_, bool luma) : lg(lg_), gx2(2 * gx), gy2(2 * gy)
+        {
+            first = gx + gy == 0;
+            if (lg == 3) {
+                off = luma ? 9 : 6;
+                dc_ctx = off + 10;
+                far = false;
+                far_ctx = near_base = 0;
+            } else {
+                off = luma ? 20 : 17;
+                dc_ctx = off;
+                far = gx + gy >= 3 * (n >> 4);
+                far_ctx = luma ? 24 : 18;
+                near_base = ((luma && !first) ? 4 : 1) + off;
+            }
         }
-        const int off = luma ? 20 : 17;
-        if (x + y == 0) return off;
-        if ((x >> 2) + (y >> 2) >= 3 * (n >> 4)) return luma ? 24 : 18;
-        const uint32_t r0 = row[y] >> x, r1 = row[y + 1] >> x, r2 = row[y + 2] >> x;
-        int cnt = (int)((r0 >> 1) & 1u) + (int)((r1 >> 1) & 1u) + (int)((r0 >> 2) & 1u);
-        if (((x & 3) || (y & 3)) && (((x + 1) & 3) || ((y + 2) & 3))) cnt += (int)(r1 & 1u);
-        if (cnt < 4) cnt += (int)(r2 & 1u);
-        cnt = (cnt + 1) >> 1;
-        return ((luma && (x >> 2) + (y >> 2) > 0) ? 4 : 1) + off + cnt;
-    }
+        int ctx(const uint32_t *win, int dx, int dy) const
+        {
+            if (first && dx + dy == 0) return dc_ctx;
+            if (lg == 3) {
+                static const uint8_t map[16] = {0, 1, 2, 3, 4, 5, 6, 3, 8, 6, 6, 7, 9, 9, 7, 7};
+                return off + map[4 * (gy2 + (dy >> 1)) + gx2 + (dx >> 1)];
+            }
+            if (far) return far_ctx;
+            const uint32_t r0 = win[dy] >> dx, r1 = win[dy + 1] >> dx, r2 = win[dy + 2] >> dx;
+            int cnt = (int)((r0 >> 1) & 1u) + (int)((r1 >> 1) & 1u) + (int)((r0 >> 2) & 1u);
+            if ((dx || dy) && (((dx + 1) & 3) || ((dy + 2) & 3))) cnt += (int)(r1 & 1u);
+            if (cnt < 4) cnt += (int)(r2 & 1u);
+            return near_base + ((cnt + 1) >> 1);
+        }
+    };
 
     // xWriteGoRiceExGolomb + xWriteEpExGolomb (src/bitstream.cpp:777-828)
     void remainder(uint32_t v, uint32_t &rice)
