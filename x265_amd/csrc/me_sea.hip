@@ -32,10 +32,10 @@ namespace x265amd {
 // so that one v_sad_u16 adds both |differences| to the candidate's bound.
 //
 // One kernel, one pass over the picture: a workgroup makes a 112 x 64 tile of P.  (1) horizontal 16-sums
-// H16 of the 128 columns x 79 rows the tile needs, 4 outputs per item from 5 dwords of pixels, into LDS;
+// H16 of the 128 columns x 79 rows the tile needs, 8 outputs per item from 6 dwords of pixels, into LDS;
 // (2) vertical running sums down the columns -- a thread owns a column pair (packed u16) and a quarter of
 // the rows -- into LDS; (3) pairs out, 8 bytes per lane.  HBM: 1.5 B/px read, 4 B/px written (two kernels
-// with H16 in memory moved 9.5 B/px).
+// with H16 in memory moved 9.5 B/px).  (3) writes 16 bytes per lane.
 constexpr int kBoxTW = 112, kBoxTH = 64;   // tile of P
 constexpr int kBoxPitch = 136;             // u16 per LDS row: 272 B, a multiple of 8
 // S = side of the sub-blocks: 16 for the 64x64 search, 8 for the 32x32 search (a quarter of the block either way)
@@ -59,20 +59,24 @@ __global__ __launch_bounds__(256) void box16_pairs(const uint8_t *__restrict__ r
 
     // (1) H[r][c] = sum_{k<S} p[y0 + r][x0 + c + k]; pixels outside the picture count as 0 (sums that
     //     include them belong to sub-blocks no legal candidate uses)
-    for (int i = tid; i < kBoxRows * (kBoxCols / 4); i += 256) {
-        const int r = i / (kBoxCols / 4), gq = i - r * (kBoxCols / 4);
-        const int y = y0 + r, x = x0 + 4 * gq;
-        uint32_t d[ND];
+    static_assert(kBoxCols % 8 == 0, "eight outputs per item");
+    for (int i = tid; i < kBoxRows * (kBoxCols / 8); i += 256) {
+        const int r = i / (kBoxCols / 8), go = i - r * (kBoxCols / 8);
+        const int y = y0 + r, x = x0 + 8 * go;
+        uint32_t d[ND + 1];  // the pixels under eight neighbouring S-sums
 #pragma unroll
-        for (int k = 0; k < ND; k++)
+        for (int k = 0; k < ND + 1; k++)
             d[k] = (y < height && x + 4 * k + 4 <= width) ? *reinterpret_cast<const uint32_t *>(ref + (int64_t)y * stride + x + 4 * k) : 0u;
-        uint32_t s0 = 0;
+        uint32_t o[8];
+        o[0] = 0;
 #pragma unroll
-        for (int k = 0; k < ND - 1; k++) s0 = __builtin_amdgcn_sad_u8(d[k], 0u, s0);
-        const uint32_t s1 = s0 - (d[0] & 255u) + (d[ND - 1] & 255u);
-        const uint32_t s2 = s1 - ((d[0] >> 8) & 255u) + ((d[ND - 1] >> 8) & 255u);
-        const uint32_t s3 = s2 - ((d[0] >> 16) & 255u) + ((d[ND - 1] >> 16) & 255u);
-        *reinterpret_cast<uint2 *>(&Ht[r][4 * gq]) = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+        for (int k = 0; k < ND - 1; k++) o[0] = __builtin_amdgcn_sad_u8(d[k], 0u, o[0]);
+#pragma unroll
+        for (int j = 1; j < 8; j++) {  // slide by one pixel: byte j - 1 leaves, byte j - 1 + S enters
+            const int out = j - 1, in = j - 1 + S;
+            o[j] = o[j - 1] - ((d[out >> 2] >> (8 * (out & 3))) & 255u) + ((d[in >> 2] >> (8 * (in & 3))) & 255u);
+        }
+        *reinterpret_cast<uint4 *>(&Ht[r][8 * go]) = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
     }
     __syncthreads();
 
@@ -98,15 +102,17 @@ __global__ __launch_bounds__(256) void box16_pairs(const uint8_t *__restrict__ r
     }
     __syncthreads();
 
-    // (3) pairs out: P[y][x] = B[y][x] | B[y][x + S] << 16, two columns (8 bytes) per item
-    for (int i = tid; i < kBoxTH * (kBoxTW / 2); i += 256) {
-        const int r = i / (kBoxTW / 2), c = i - r * (kBoxTW / 2);
-        const int y = y0 + r, x = x0 + 2 * c;
-        if (y + S > height || x + 2 > width) continue;
-        const uint32_t an = *reinterpret_cast<const uint32_t *>(&Bt[r][2 * c]);
-        const uint32_t af = *reinterpret_cast<const uint32_t *>(&Bt[r][2 * c + S]);
-        *reinterpret_cast<uint2 *>(pbuf + ((int64_t)pl * height + y) * width + x) =
-            make_uint2((an & 0xffffu) | (af << 16), (an >> 16) | (af & 0xffff0000u));
+    // (3) pairs out: P[y][x] = B[y][x] | B[y][x + S] << 16, four columns (16 bytes) per item
+    static_assert(kBoxTW % 4 == 0, "four columns per item");
+    for (int i = tid; i < kBoxTH * (kBoxTW / 4); i += 256) {
+        const int r = i / (kBoxTW / 4), c = i - r * (kBoxTW / 4);
+        const int y = y0 + r, x = x0 + 4 * c;
+        if (y + S > height || x + 4 > width) continue;  // the width is a multiple of 4 (of the block side, in fact)
+        const uint2 an = *reinterpret_cast<const uint2 *>(&Bt[r][4 * c]);
+        const uint2 af = *reinterpret_cast<const uint2 *>(&Bt[r][4 * c + S]);
+        *reinterpret_cast<uint4 *>(pbuf + ((int64_t)pl * height + y) * width + x) =
+            make_uint4((an.x & 0xffffu) | (af.x << 16), (an.x >> 16) | (af.x & 0xffff0000u), (an.y & 0xffffu) | (af.y << 16),
+                       (an.y >> 16) | (af.y & 0xffff0000u));
     }
 }
 
