@@ -4,7 +4,7 @@ per round:  python tools/collect_profiles.py r2
   bench lines           -> profiles/<round>_<workload>_bench.json
   rocprofv3 kernel stats-> profiles/<round>_<workload>_kernel_stats.csv
   PMC traffic           -> profiles/pmc_traffic.json (the file bench.py reads) and profiles/<round>_pmc_traffic.json
-  SQ counter summaries  -> profiles/<round>_pmc_sq.json
+  SQ counter summaries  -> profiles/<round>_pmc_sq.json, profiles/<round>_pmc_sq_intra1080p.json
   PU search / intra frame timings, TQ wave trace -> profiles/<round>_{pu_bench,intra_bench,tq_trace}.txt"""
 import glob
 import json
@@ -48,6 +48,10 @@ def main():
     if sq:
         with open(os.path.join(DST, f"{rnd}_pmc_sq.json"), "w") as o:
             json.dump(sq, o, indent=1, sort_keys=True)
+        n += 1
+    p = os.path.join(ROOT, "gpurun_out", "pmcsq_intra1080p", "pmc_sq.json")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(DST, f"{rnd}_pmc_sq_intra1080p.json"))
         n += 1
     for name in ("pu_bench", "intra_bench", "tq_trace", "encode_i_bench"):
         p = os.path.join(SRC, name + ".txt")

@@ -44,6 +44,7 @@ pmc)
 sq)
   bash tools/run_pmc_sq.sh 1080p 2 1 > $OUT/sq_1080p.log 2>&1; echo "sq 1080p done"
   bash tools/run_pmc_tq.sh tq1080p 3 1 > $OUT/sq_tq.log 2>&1; echo "sq tq done"
+  bash tools/run_pmc_sq.sh intra1080p 2 1 > $OUT/sq_intra1080p.log 2>&1; echo "sq intra1080p done"
   ;;
 *) echo "usage: $0 bench|trace|pmc|sq"; exit 2;;
 esac
