@@ -4,11 +4,16 @@ inputs.  Bit-exact everywhere (integer / byte / index work).
 
 Run on the MI355X box:  python -u -m pytest tests -m gpu -x -v
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 from conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -965,3 +970,19 @@ def test_intra_api_rejects_wrong_output_buffers(gpu):
     one = api.intra_frame_buffers(h, w, cu, y.device)
     with pytest.raises(ValueError):
         gpu.intra_encode_frame(y.contiguous(), u.contiguous(), v.contiguous(), cu, 30, out=dict(one, level_u=one["level_y"]))
+
+
+def test_me_random_geometries(gpu, oracle):
+    """tools/me_fuzz.py, 16 cases: random picture sizes, block sides 64 / 32, ranges 1 .. 128, frames x references, row
+    strides wider than the picture, noise / flat / shifted content -- the elimination search and the one-candidate-
+    per-lane kernel equal the every-candidate kernel, and a sample of blocks equals the CPU oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("me_fuzz", os.path.join(ROOT, "tools", "me_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    try:
+        sys.argv = ["me_fuzz.py", "16", "3"]
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
