@@ -986,3 +986,19 @@ def test_me_random_geometries(gpu, oracle):
         assert mod.main() == 0
     finally:
         sys.argv = argv
+
+
+def test_tq_random_geometries(gpu, oracle):
+    """tools/tq_fuzz.py, 24 cases: random plane sizes (multiples of the TU, not of the 32x32 work tile), TU 4 .. 32, QP
+    0 .. 51, all three roundings, odd row strides, extreme residuals, per-TU modes at 4x4 -- forward, inverse and the
+    fused round trip agree with each other and with the CPU oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tq_fuzz", os.path.join(ROOT, "tools", "tq_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    try:
+        sys.argv = ["tq_fuzz.py", "24", "9"]
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
