@@ -675,7 +675,8 @@ def test_intra_frame_cfg1_reconstruction_md5(gpu, oracle):
             np.testing.assert_array_equal(lvl, lv)
 
 
-@pytest.mark.parametrize("w,h,cu,qp", [(416, 224, 32, 27), (128, 96, 32, 12), (96, 64, 16, 45), (32, 32, 32, 30), (16, 48, 16, 22)])
+@pytest.mark.parametrize("w,h,cu,qp", [(416, 224, 32, 27), (128, 96, 32, 12), (96, 64, 16, 45), (32, 32, 32, 30), (16, 48, 16, 22),
+                                        (32, 96, 32, 12), (64, 32, 32, 40), (32, 64, 16, 33)])
 def test_intra_frame_vs_oracle(gpu, oracle, w, h, cu, qp):
     """Other sizes (CU 32, a single CU, a single column), quantisers and content against the oracle's restatement
     of the loop: reconstruction, modes, levels, xQuant sums."""
@@ -999,6 +1000,22 @@ def test_tq_random_geometries(gpu, oracle):
     argv = sys.argv
     try:
         sys.argv = ["tq_fuzz.py", "24", "9"]
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
+
+
+def test_intra_random_geometries(gpu, oracle):
+    """tools/intra_fuzz.py, 12 cases: random picture sizes (one CU wide or high included), CU 16 / 32, QP 0 .. 51,
+    batches of 1 .. 5 frames of noise, flat, smooth and blocky content -- reconstruction, levels and modes of
+    x265amd_intra_encode_frames equal the oracle's restatement of the loop."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("intra_fuzz", os.path.join(ROOT, "tools", "intra_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    try:
+        sys.argv = ["intra_fuzz.py", "12", "3"]
         assert mod.main() == 0
     finally:
         sys.argv = argv

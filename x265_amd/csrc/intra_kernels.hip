@@ -748,6 +748,7 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
         // the transform stage follows the diagonal: only the tile units that hold its CUs
         const int lo = d - (ncx - 1) > 0 ? (d - (ncx - 1) + 1) / 2 : 0;
         const int hi = d / 2 < ncy - 1 ? d / 2 : ncy - 1;
+        if (hi < lo) continue;  // a picture one CU wide has no CU on its odd diagonals (a count of 0 would mean "the whole plane")
         const TqDiag dy{hi - lo + 1, d, lo, l2}, dc{hi - lo + 1, d, lo, l2 - 1, pair.fgroup, pair.fmul, pair.sum_pair};
         if (fused_ok) {
             // prediction and transform stage of the step as one launch
