@@ -1019,3 +1019,19 @@ def test_intra_random_geometries(gpu, oracle):
         assert mod.main() == 0
     finally:
         sys.argv = argv
+
+
+def test_pu_random_geometries(gpu, oracle):
+    """tools/pu_fuzz.py, 8 cases: the square-PU tree and the all-shapes search on random picture sizes, ranges 1 .. 128,
+    frames x references and content -- squares 64 / 32 / 16 equal the every-candidate search at that block size, the
+    rectangles and 8x8 equal the CPU oracle on a sample of blocks."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pu_fuzz", os.path.join(ROOT, "tools", "pu_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    try:
+        sys.argv = ["pu_fuzz.py", "8", "4"]
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
