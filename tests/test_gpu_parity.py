@@ -1035,3 +1035,19 @@ def test_pu_random_geometries(gpu, oracle):
         assert mod.main() == 0
     finally:
         sys.argv = argv
+
+
+def test_gop_random_geometries(gpu, oracle):
+    """tools/gop_fuzz.py, 5 cases: whole GOP segments (the I picture through the intra path, two P pictures in closed
+    loop, luma and chroma) on random picture sizes, ranges, quantisers, segment counts and intra CU sizes against the
+    same chain on the CPU oracle: vectors, levels and every reconstructed picture."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gop_fuzz", os.path.join(ROOT, "tools", "gop_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    argv = sys.argv
+    try:
+        sys.argv = ["gop_fuzz.py", "5", "8"]
+        assert mod.main() == 0
+    finally:
+        sys.argv = argv
