@@ -39,25 +39,38 @@ def main():
         modes = None
         if tu == 4 and rng.integers(0, 2):
             modes = rng.choice(np.array([0, 1, 2, 10, 11, 25, 26, 34, 255], np.uint8), (f, (h // 4) * (w // 4)))
+        # motion-compensated prediction: one vector per mv_ctu x mv_ctu block, every block stays inside the plane
+        mv = mvt = None
+        mv_ctu = int(rng.choice([16, 32, 64]))
+        if tu <= mv_ctu and w % mv_ctu == 0 and h % mv_ctu == 0 and modes is None and rng.integers(0, 2):
+            ncx, ncy = w // mv_ctu, h // mv_ctu
+            mv = np.zeros((f, ncy * ncx), pyoracle.MV_DTYPE)
+            for i in range(f):
+                for c in range(ncy * ncx):
+                    cx, cy = (c % ncx) * mv_ctu, (c // ncx) * mv_ctu
+                    mv[i, c]["mvx"] = int(rng.integers(-cx, w - mv_ctu - cx + 1))
+                    mv[i, c]["mvy"] = int(rng.integers(-cy, h - mv_ctu - cy + 1))
+            mvt = torch.from_numpy(mv.view(np.int32).reshape(f, ncy * ncx, 2)).cuda()
         sbuf = torch.zeros((f, h, w + pad_s), dtype=torch.uint8, device="cuda")
         pbuf = torch.zeros((f, h, w + pad_p), dtype=torch.uint8, device="cuda")
         sbuf[:, :, :w] = torch.from_numpy(src).cuda()
         pbuf[:, :, :w] = torch.from_numpy(pred).cuda()
         sv, pv = sbuf[:, :, :w], pbuf[:, :, :w]
         md = torch.from_numpy(modes).cuda() if modes is not None else None
-        level, sums, rec = gpu.tq_roundtrip(sv, pv, tu, qp, sl, modes=md)
-        lf, sf = gpu.tq_forward(sv, pv, tu, qp, sl, modes=md)
-        ri = gpu.tq_inverse(lf, pv, tu, qp, sl, modes=md)
+        level, sums, rec = gpu.tq_roundtrip(sv, pv, tu, qp, sl, modes=md, mv=mvt, mv_ctu=mv_ctu)
+        lf, sf = gpu.tq_forward(sv, pv, tu, qp, sl, modes=md, mv=mvt, mv_ctu=mv_ctu)
+        ri = gpu.tq_inverse(lf, pv, tu, qp, sl, modes=md, mv=mvt, mv_ctu=mv_ctu)
         level, sums, rec, lf, sf, ri = (t.cpu().numpy() for t in (level, sums, rec, lf, sf, ri))
         ok = np.array_equal(level, lf) and np.array_equal(sums, sf) and np.array_equal(rec, ri)
         for i in range(f):
             m = modes[i] if modes is not None else None
-            ol, os_ = orc.tq_forward(src[i], pred[i], tu, qp, sl, modes=m)
-            orec = orc.tq_inverse(ol, pred[i], tu, qp, sl, modes=m)
+            mvi = np.ascontiguousarray(mv[i]) if mv is not None else None
+            ol, os_ = orc.tq_forward(src[i], pred[i], tu, qp, sl, modes=m, mv=mvi, mv_ctu=mv_ctu)
+            orec = orc.tq_inverse(ol, pred[i], tu, qp, sl, modes=m, mv=mvi, mv_ctu=mv_ctu)
             ok = ok and np.array_equal(level[i], ol) and np.array_equal(sums[i].ravel().astype(np.uint32), os_) and np.array_equal(rec[i], orec)
         bad += not ok
         print(f"case {case}: {w}x{h} x{f} tu {tu} qp {qp} slice {sl} strides +{pad_s}/+{pad_p} {kind}"
-              f"{' modes' if modes is not None else ''}: {'ok' if ok else 'MISMATCH'}", flush=True)
+              f"{' modes' if modes is not None else ''}{f' vectors per {mv_ctu}' if mv is not None else ''}: {'ok' if ok else 'MISMATCH'}", flush=True)
     print(f"{cases} cases, {bad} mismatches")
     return 1 if bad else 0
 
