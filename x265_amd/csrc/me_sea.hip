@@ -161,10 +161,11 @@ constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or alread
 __device__ __forceinline__ uint32_t lb_store(uint32_t lb) { return lb >> 4; }
 
 struct SeaHdr {  // per (plane, CTU)
-    uint32_t n0;        // groups in the first batch (<= kFirst)
-    uint32_t rest_min;  // smallest stored bound among the groups NOT in it (kNone: none left)
-    uint32_t est;       // work estimate: groups with a bound <= the probed SAD (an upper bound of n0 + second pass)
-    uint32_t pad;
+    uint32_t n0_rest;    // low half: groups in the first batch (<= kFirst); high half: smallest stored bound among the
+                         // groups NOT in it (kNone: none left)
+    uint32_t est;        // work estimate: groups with a bound <= the probed SAD (an upper bound of n0 + second pass)
+    uint32_t probe_sad;  // the probe's best candidate: its exact SAD and raster index -- where kernel 2's search starts
+    uint32_t probe_idx;  // (0xffffffff / 0xffffffff: no probe)
 };
 constexpr int kFirst = 256;   // first batch: two rounds of 128 groups
 constexpr int kMaxWgLists = 512;  // persistent workgroups that may need a schedule slice in the workspace
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     __shared__ uint32_t hist[kBins];
     __shared__ uint32_t csum[16];
     __shared__ int list_n, eq_n, pick_bin, below_n, est_n;
-    __shared__ uint32_t min_key, probe_sad, pref[kBins];
+    __shared__ uint32_t min_key, probe_sad, probe_idx, pref[kBins];
     __shared__ uint32_t rest_lb;
     __shared__ uint32_t bank_cnt[32];
     __shared__ uint16_t sel_ent[kFirst];
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         //      groups with a bound <= UB are an upper bound of everything kernel 2 will have to
         //      evaluate: its work estimate. ----
         const uint32_t key = min_key;
-        uint32_t ub = 0xffffffffu;
+        unsigned long long ubk = ~0ull;  // exact SAD << 32 | raster index of the best member
         if (key != 0xffffffffu) {  // block-uniform
             const int gi = (int)(key & 0xffffu);
             const int dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
@@ -430,10 +431,17 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) sq += (uint32_t)__shfl_xor((int)sq, o);
                 const int dxi = 4 * gx + q - a;
-                if (dxi >= 0 && dxi < ndx) ub = min(ub, sq);
+                if (dxi >= 0 && dxi < ndx) {
+                    const unsigned long long k = ((unsigned long long)sq << 32) |
+                                                 (unsigned)((L.dylo + dyi + g.range) * (2 * g.range + 1) + L.dxlo + dxi + g.range);
+                    ubk = k < ubk ? k : ubk;
+                }
             }
         }
-        if (tid == 64) probe_sad = ub;
+        if (tid == 64) {
+            probe_sad = (uint32_t)(ubk >> 32);
+            probe_idx = (uint32_t)ubk;
+        }
     } else
     for (int v0 = 0; v0 < nvec; v0 += kBoundsThreads - 64) {
         if (v0 + (wtid & ~63) >= nvec) break;  // nothing left for this wave (wave-uniform; no barrier inside)
@@ -520,10 +528,10 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         const uint32_t ubs = ub == 0xffffffffu ? 0u : min(ub >> 4, 0xfffeu);  // same units as the stored bounds
         est_n = (int)pref[min(lb_bin(ubs), kBins - 1)];
         SeaHdr h;
-        h.n0 = (uint32_t)n0;
-        h.rest_min = rest_lb;  // kNone: nothing left over
+        h.n0_rest = (uint32_t)n0 | (rest_lb << 16);  // kNone: nothing left over
         h.est = (uint32_t)est_n;
-        h.pad = 0;
+        h.probe_sad = ub;
+        h.probe_idx = probe_idx;
         hdr[ctu_id] = h;
         // launch order of kernel 2: longest first, in kClasses classes of the estimate (a queue each)
         if (stats) {
@@ -537,12 +545,80 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     }
 }
 
+// One wave's part of a half round of kernel 2: the B / 4 block rows from `row0` on (wave-uniform) of the lanes' groups
+// (`ent` = dyi * ngx + gx, valid where `have`): partial SADs of the four members to `dst` (the lane's 16 bytes of part[]).
+// The current rows are wave-uniform: s_load into SGPRs, the scalar operand of v_qsad_pk_u16_u8.
+template <int B>
+__device__ __forceinline__ void sea_half_partial(const uint32_t *__restrict__ win, int pitch, int ngx,
+                                                 const uint32_t *__restrict__ cbase, int cstr, uint32_t *__restrict__ dst,
+                                                 int ent, bool have, int row0)
+{
+    if (__ballot(have) == 0ull) return;  // wave-uniform
+    ent = have ? ent : 0;
+    const int dyi = ent / ngx, gx = ent - dyi * ngx;
+    constexpr int RQ = B / 4, NW = B / 4;  // rows of a quarter of the block, dwords of a block row
+    const uint32_t *wrow = win + (dyi + row0) * pitch + gx;
+    const uint32_t *crow = cbase + row0 * cstr;
+    uint32_t acc32[4] = {0u, 0u, 0u, 0u};
+    // two-row software pipeline: the loads of row r+1 (NW + 1 window dwords by ds_read2,
+    // NW current dwords by s_load) are in flight while row r's NW qsads issue
+    uint32_t dA[NW + 1], dB[NW + 1], SA[NW], SB[NW];
+    uint64_t acc16 = 0;
+#define SEA_LOAD(r, d, S)                                                   \
+    {                                                                       \
+        const uint32_t *p_ = wrow + (r) * pitch;                            \
+        _Pragma("unroll") for (int k = 0; k < NW + 1; k++) d[k] = p_[k];    \
+        _Pragma("unroll") for (int k = 0; k < NW; k++) S[k] = crow[(r) * cstr + k]; \
+    }
+#define SEA_ROW(d, S)                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < NW; k++)                                                     \
+        acc16 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], S[k], acc16);
+    SEA_LOAD(0, dA, SA)
+#pragma unroll
+    for (int r = 0; r < RQ; r += 2) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): row r has landed ...
+        SEA_LOAD(r + 1, dB, SB)              // ... row r+1 goes out before row r's qsads
+        __builtin_amdgcn_sched_barrier(0);
+        SEA_ROW(dA, SA)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        if (r + 2 < RQ) SEA_LOAD(r + 2, dA, SA)
+        __builtin_amdgcn_sched_barrier(0);
+        SEA_ROW(dB, SB)
+        __builtin_amdgcn_sched_barrier(0);
+        if ((r & 3) == 2) {  // every 4 rows: at most 64 qsads * 1020 < 2^16
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
+            acc16 = 0;
+        }
+    }
+#undef SEA_LOAD
+#undef SEA_ROW
+    *reinterpret_cast<uint4 *>(dst) = make_uint4(acc32[0], acc32[1], acc32[2], acc32[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Kernel 2: exact SADs.  Window in LDS.  Round = 128 groups: a lane = one group (4 dx at one dy) x 16
-// rows, 8 waves = 2 sets of 64 groups x 4 row quarters; the quarter-0 wave of each set merges the
-// partial sums (double-buffered through LDS: one barrier per round).  The first batch (<= 2 rounds)
-// comes from list0 with its entries already in registers when the window has landed; a second pass is
-// needed only if a group outside it has a bound <= the best SAD found (hdr.rest_min tells without a scan).
+// Kernel 2: exact SADs.  Window in LDS.  Everything runs in HALF ROUNDS: a lane = one group (4 dx at one dy) x
+// B / 4 rows, a pair of waves = 64 groups x the two row quarters of ONE half of the block, so the WAVES waves
+// take 32 x WAVES groups' upper (or lower) halves at a time; the even wave of a pair adds the two quarters up
+// (double-buffered through LDS: one barrier per half round).
+//
+// A partial SAD is a lower bound of the whole one.  A group whose legal members all exceed the best SAD found
+// so far on the UPPER half of the block alone is dropped there -- exactly as a bound drops it: no winner and no
+// tie is lost.  The others are kept (group + four partial SADs, 18 bytes, in LDS) and finished by lower-half
+// rounds.
+//
+// Pass 0 = the first batch (list0; its entries are in registers when the window has landed).  The search starts
+// from the exact SAD the bounds kernel's probe measured (a real candidate's key).  Upper halves of the whole
+// batch; then the lower halves of tier 1 = the groups within an eighth of the smallest partial SAD (on typical
+// content: the true match and little else), which gives a tight best SAD; then of tier 2 = whatever of the
+// rest still has a partial SAD under it (typically nothing).  Pass 1, only if a group outside the batch has a
+// bound <= the best SAD (hdr.rest_min tells without a scan): one sweep over the bounds builds the schedule, half
+// rounds over it with the kept groups finished whenever half a round's worth has gathered.
+//
+// Ties: a group whose bound EQUALS the best SAD can at most tie it, and a tie is won by the lower raster index
+// (the reference's strict `<` in raster order, src/encode.cpp:762-765): such a group is scheduled only if its
+// first legal member comes before the current winner in raster order.
 // ---------------------------------------------------------------------------------------------
 template <bool kStats, int WAVES, int B>
 __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t *__restrict__ cur_base,
@@ -554,33 +630,34 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                                                                    const uint32_t *__restrict__ order,
                                                                    uint32_t *__restrict__ ctrl, int total,
                                                                    x265amd_mv *__restrict__ out, const MeGeom g,
-                                                                   int gl_pitch, int win_dwords, int surv_cap,
+                                                                   int gl_pitch, int win_dwords, int surv_off, int surv_cap,
                                                                    uint32_t *__restrict__ stats)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *win = smem;                                                     // [win_rows][pitch] reference window
-    constexpr int kThreads = WAVES * 64, kRound = 16 * WAVES;  // WAVES / 4 sets of 64 groups per round
+    constexpr int kThreads = WAVES * 64, kHalf = 32 * WAVES;  // groups of a half round: WAVES / 2 sets of 64
+    static_assert(kFirst <= kHalf, "the first batch is one half round");
     // second-pass schedule: in LDS behind the window (8 waves), or in this workgroup's own slice of the
     // workspace when the LDS is needed for a +-128 window and 16 waves' partial sums (same-CU L1: coherent
     // across the barrier for the waves of one workgroup)
     uint16_t *list = WAVES == 8 ? reinterpret_cast<uint16_t *>(smem + win_dwords) : wg_list + (size_t)blockIdx.x * gl_pitch;
+    uint32_t *surv_sum = smem + surv_off;                                          // [surv_cap][4] upper-half SADs of the kept groups
+    uint16_t *surv_ent = reinterpret_cast<uint16_t *>(surv_sum + 4 * surv_cap);    // [surv_cap] the groups
     __shared__ __attribute__((aligned(16))) uint32_t part[2][WAVES * 64 * 4];  // partial SADs: [round & 1][wave][lane][4 dx]
     __shared__ unsigned long long best_key;
     __shared__ int list_n, next_ctu, surv_n;
-    // 16-wave shape, second pass: groups that outlived the upper half of the block (see below), behind the window
-    [[maybe_unused]] uint32_t *surv_sum = smem + ((win_dwords + 3) & ~3);                        // [surv_cap][4] upper-half SADs
-    [[maybe_unused]] uint16_t *surv_ent = reinterpret_cast<uint16_t *>(surv_sum + 4 * surv_cap);  // [surv_cap] their groups
+    __shared__ uint32_t u_min;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: keeps the current rows in SGPRs
-    const int set = wave >> 2, qtr = wave & 3;
+    const int hset = wave >> 1, hq = wave & 1;                  // 64 groups a set; the two quarters of a half
     const int R = g.range;
     const int span = 2 * R + 1;
     const int cstr = g.stride >> 2;
     const int per_plane = g.ctus_x * g.ctus_y;
     int round = 0;
 
-    // Persistent workgroups: each takes the next CTU of the launch order (ctrl[2] counts them out) until
+    // Persistent workgroups: each takes the next CTU of the launch order (ctrl[kClasses] counts them out) until
     // none is left -- every wave reaches that exit.  The index of the NEXT CTU is fetched while this
     // one is being searched.
     uint32_t cls_end[kClasses];  // running ends of the class queues in hand-out order (final: kernel 1 is done)
@@ -592,7 +669,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             cls_end[c] = acc;
         }
     }
-    auto item_ctu = [&](int it) -> uint32_t {  // it < total
+    const int nitems = (int)cls_end[kClasses - 1];  // CTUs queued for this kernel (the others went to the every-candidate list)
+    auto item_ctu = [&](int it) __attribute__((always_inline)) -> uint32_t {  // it < nitems
         int c = 0;
         uint32_t beg = 0;
 #pragma unroll
@@ -606,7 +684,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     int it_now = 0;  // (thread 0) position of the current CTU in the hand-out order
     if (tid == 0) {
         it_now = (int)atomicAdd(&ctrl[kClasses], 1u);
-        next_ctu = it_now < total ? (int)item_ctu(it_now) : -1;
+        next_ctu = it_now < nitems ? (int)item_ctu(it_now) : -1;
     }
     __syncthreads();
     int ctu_now = next_ctu;
@@ -614,13 +692,13 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     // The next CTU's index is fetched while this one is searched -- but only when this one is light.  A
     // workgroup that reserves its next CTU while it starts on one of the two heaviest classes may reserve
     // another of them (the queues' heads go out within microseconds of the launch) and run the two
-    // back to back: 1.0 M + 0.5 M cycles on one workgroup while the kernel's mean per CU is 1.09 M.
+    // back to back.
     int it_next = 0;
     uint32_t ctu_next_v = 0;
     const bool reserve = tid == 0 && (uint32_t)it_now >= cls_end[1];
     if (reserve) {
         it_next = (int)atomicAdd(&ctrl[kClasses], 1u);
-        ctu_next_v = item_ctu(it_next < total ? it_next : 0);
+        ctu_next_v = item_ctu(it_next < nitems ? it_next : 0);
     }
     const int64_t ctu_id = ctu_now;
     const int plane = ctu_now / per_plane, cin = ctu_now - plane * per_plane;
@@ -633,12 +711,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     const uint16_t *glo = gl + ctu_id * gl_pitch;
     const uint16_t *l0 = list0 + ctu_id * gl_pitch;
 
-    // the first batch's entries of this lane (rounds 0 and 1) and the header: in flight with the window
+    // the first batch's entry of this lane and the header: in flight with the window
     const long long t_begin = kStats ? clock64() : 0;
-    const int e_hi = gl_pitch - 1;
-    int ent0[kFirst / kRound];
-#pragma unroll
-    for (int r = 0; r < kFirst / kRound; r++) ent0[r] = (int)l0[min(r * kRound + set * 64 + lane, e_hi)];
+    const int slot0 = hset * 64 + lane;
+    const int ent0 = (int)l0[min(slot0, gl_pitch - 1)];
     const SeaHdr h = hdr[ctu_id];
 
     // ---- stage the reference window: a wave per row, a lane per dword, 13 rows in flight ----
@@ -665,155 +741,135 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         }
     }
     if (tid == 0) {
-        best_key = ~0ull;
+        best_key = ((unsigned long long)h.probe_sad << 32) | h.probe_idx;  // the probe's candidate: evaluated exactly by kernel 1
         list_n = 0;
+        surv_n = 0;
+        u_min = 0xffffffffu;
     }
-    const int n0 = __builtin_amdgcn_readfirstlane((int)h.n0);
-    const uint32_t rest_min = __builtin_amdgcn_readfirstlane(h.rest_min);
+    const int n0 = __builtin_amdgcn_readfirstlane((int)(h.n0_rest & 0xffffu));
+    const uint32_t rest_min = __builtin_amdgcn_readfirstlane(h.n0_rest >> 16);
     __syncthreads();
 
     const long long t_staged = kStats ? clock64() : 0;
     const uint32_t *__restrict__ cbase = reinterpret_cast<const uint32_t *>(cur + (int64_t)cy * g.stride + cx);
 
-    // one round for this wave: `ent` = the lane's group (valid where `have`)
-    auto run_round = [&](int ent, bool have) {
-        ent = have ? ent : 0;
-        const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx;
-        uint32_t *pbuf = part[round & 1];
-        if (__ballot(have) != 0ull) {  // wave-uniform
-            constexpr int RQ = B / 4, NW = B / 4;  // rows of a quarter of the block, dwords of a block row
-            const uint32_t *wrow = win + (dyi + RQ * qtr) * L.pitch + gx;
-            const uint32_t *crow = cbase + (RQ * qtr) * cstr;
-            uint32_t acc32[4] = {0u, 0u, 0u, 0u};
-            // two-row software pipeline: the loads of row r+1 (NW + 1 window dwords by ds_read2,
-            // NW current dwords by s_load) are in flight while row r's NW qsads issue
-            uint32_t dA[NW + 1], dB[NW + 1], SA[NW], SB[NW];
-            uint64_t acc16 = 0;
-#define SEA_LOAD(r, d, S)                                                   \
-    {                                                                       \
-        const uint32_t *p_ = wrow + (r) * L.pitch;                          \
-        _Pragma("unroll") for (int k = 0; k < NW + 1; k++) d[k] = p_[k];    \
-        _Pragma("unroll") for (int k = 0; k < NW; k++) S[k] = crow[(r) * cstr + k]; \
-    }
-#define SEA_ROW(d, S)                                                                                   \
-    _Pragma("unroll") for (int k = 0; k < NW; k++)                                                     \
-        acc16 = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], S[k], acc16);
-            SEA_LOAD(0, dA, SA)
-#pragma unroll
-            for (int r = 0; r < RQ; r += 2) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): row r has landed ...
-                SEA_LOAD(r + 1, dB, SB)              // ... row r+1 goes out before row r's qsads
-                __builtin_amdgcn_sched_barrier(0);
-                SEA_ROW(dA, SA)
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                if (r + 2 < RQ) SEA_LOAD(r + 2, dA, SA)
-                __builtin_amdgcn_sched_barrier(0);
-                SEA_ROW(dB, SB)
-                __builtin_amdgcn_sched_barrier(0);
-                if ((r & 3) == 2) {  // every 4 rows: at most 64 qsads * 1020 < 2^16
-#pragma unroll
-                    for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
-                    acc16 = 0;
-                }
-            }
-            *reinterpret_cast<uint4 *>(&pbuf[(wave * 64 + lane) * 4]) = make_uint4(acc32[0], acc32[1], acc32[2], acc32[3]);
-        }
-        __syncthreads();
-        if (qtr == 0 && __ballot(have) != 0ull) {  // the set's quarter-0 wave adds the four quarters up
-            unsigned long long k = ~0ull;
-            if (have) {
-                const int dy = L.dylo + dyi;
-                uint4 s = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const uint4 t = *reinterpret_cast<const uint4 *>(&pbuf[((wave + q4) * 64 + lane) * 4]);
-                    s.x += t.x;
-                    s.y += t.y;
-                    s.z += t.z;
-                    s.w += t.w;
-                }
-                const uint32_t sad[4] = {s.x, s.y, s.z, s.w};
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int dx = L.wx0 - cx + 4 * gx + q;
-                    if (dx >= L.dxlo && dx <= L.dxhi) {
-                        const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
-                        k = key < k ? key : k;
-                    }
-                }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(k, o);
-                k = other < k ? other : k;
-            }
-            if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
-        }
-        round++;  // the next round writes the other half of part[]: no second barrier
+    // this wave's part of a half round (sea_half_partial): the B / 4 rows from `row0` on of the lanes' groups
+    auto half_partial = [&](int ent, bool have, int row0) __attribute__((always_inline)) {
+        sea_half_partial<B>(win, L.pitch, L.ngx, cbase, cstr, part[round & 1] + (wave * 64 + lane) * 4, ent, have, row0);
     };
-
-    // ---- half rounds (16-wave shape, second pass).  Every group of the second pass has a bound under the best SAD,
-    //      but on content whose candidates differ by pixel noise most of them lose by a wide margin: their SAD over
-    //      the UPPER HALF of the block alone already exceeds the best SAD, and a partial SAD is a lower bound of the
-    //      whole one, so they can be dropped there -- exactly as a bound drops them (no winner, no tie is lost).  A half
-    //      round = 2 x kRound groups: a wave takes 64 groups x the B / 4 rows of one quarter of ONE half; the groups
-    //      whose upper half stays under the best SAD of the first batch are kept with their four partial SADs and
-    //      finished by lower-half rounds. ----
-    [[maybe_unused]] auto half_partial = [&](int ent, bool have, int row0) {
-        ent = have ? ent : 0;
-        const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx;
-        uint32_t *pbuf = part[round & 1];
-        if (__ballot(have) != 0ull) {  // wave-uniform
-            constexpr int RQ = B / 4, NW = B / 4;
-            const uint32_t *wrow = win + (dyi + row0) * L.pitch + gx;
-            const uint32_t *crow = cbase + row0 * cstr;
-            uint32_t acc32[4] = {0u, 0u, 0u, 0u};
-            uint32_t dA[NW + 1], dB[NW + 1], SA[NW], SB[NW];
-            uint64_t acc16 = 0;
-            SEA_LOAD(0, dA, SA)
-#pragma unroll
-            for (int r = 0; r < RQ; r += 2) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                SEA_LOAD(r + 1, dB, SB)
-                __builtin_amdgcn_sched_barrier(0);
-                SEA_ROW(dA, SA)
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                if (r + 2 < RQ) SEA_LOAD(r + 2, dA, SA)
-                __builtin_amdgcn_sched_barrier(0);
-                SEA_ROW(dB, SB)
-                __builtin_amdgcn_sched_barrier(0);
-                if ((r & 3) == 2) {
-#pragma unroll
-                    for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
-                    acc16 = 0;
-                }
-            }
-            *reinterpret_cast<uint4 *>(&pbuf[(wave * 64 + lane) * 4]) = make_uint4(acc32[0], acc32[1], acc32[2], acc32[3]);
-        }
-    };
-#undef SEA_LOAD
-#undef SEA_ROW
     // the two quarters of a half that the waves `wave` and `wave + 1` left in part[]
-    [[maybe_unused]] auto half_sum = [&]() -> uint4 {
+    auto half_sum = [&]() __attribute__((always_inline)) -> uint4 {
         const uint32_t *pbuf = part[round & 1];
         const uint4 a = *reinterpret_cast<const uint4 *>(&pbuf[(wave * 64 + lane) * 4]);
         const uint4 b = *reinterpret_cast<const uint4 *>(&pbuf[((wave + 1) * 64 + lane) * 4]);
         return make_uint4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     };
-
-    // ---- pass 0: the first batch ----
+    // smallest partial SAD among the legal members of a group
+    auto legal_min = [&](int ent, const uint4 s) __attribute__((always_inline)) -> uint32_t {
+        const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx;
+        const uint32_t sad[4] = {s.x, s.y, s.z, s.w};
+        uint32_t mn = 0xffffffffu;
 #pragma unroll
-    for (int r = 0; r < kFirst / kRound; r++)
-        if (r == 0 || n0 > r * kRound) run_round(ent0[r], r * kRound + set * 64 + lane < n0);
+        for (int q = 0; q < 4; q++) {
+            const int dx = L.wx0 - cx + 4 * gx + q;
+            if (dx >= L.dxlo && dx <= L.dxhi) mn = min(mn, sad[q]);
+        }
+        return mn;
+    };
+    // even waves: append the lanes with `keep` (group + upper-half SADs) to the kept list
+    auto keep_append = [&](bool keep, int ent, const uint4 sm) __attribute__((always_inline)) {
+        const unsigned long long km = __ballot(keep);
+        if (km != 0ull) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&surv_n, __popcll(km));
+            wbase = __shfl(wbase, 0);
+            if (keep) {
+                const int slot = wbase + __popcll(km & ((1ull << lane) - 1ull));
+                surv_ent[slot] = (uint16_t)ent;
+                *reinterpret_cast<uint4 *>(&surv_sum[4 * slot]) = sm;
+            }
+        }
+    };
+    // lower halves of the kept groups [from, to): their SADs are complete, the winner so far goes to best_key.
+    // Block-uniform arguments; the caller's next barrier publishes best_key.
+    auto lower_rounds = [&](int from, int to) __attribute__((always_inline)) {
+        for (int kb = from; kb < to; kb += kHalf) {
+            const int li = kb + hset * 64 + lane;
+            const bool have = li < to;
+            const int ent = have ? (int)surv_ent[li] : 0;
+            half_partial(ent, have, B / 2 + (B / 4) * hq);
+            __syncthreads();
+            if (hq == 0 && __ballot(have) != 0ull) {
+                unsigned long long k = ~0ull;
+                if (have) {
+                    const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx, dy = L.dylo + dyi;
+                    uint4 sm = half_sum();
+                    const uint4 up = *reinterpret_cast<const uint4 *>(&surv_sum[4 * li]);
+                    sm = make_uint4(sm.x + up.x, sm.y + up.y, sm.z + up.z, sm.w + up.w);
+                    const uint32_t sad[4] = {sm.x, sm.y, sm.z, sm.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int dx = L.wx0 - cx + 4 * gx + q;
+                        if (dx >= L.dxlo && dx <= L.dxhi) {
+                            const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
+                            k = key < k ? key : k;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const unsigned long long other = __shfl_xor(k, o);
+                    k = other < k ? other : k;
+                }
+                if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
+            }
+            round++;  // the next half round writes the other half of part[]: no second barrier
+        }
+    };
+
+    // ---- pass 0: the first batch.  Upper halves of all of it ... ----
+    const bool have0 = slot0 < n0;
+    half_partial(ent0, have0, (B / 4) * hq);
+    __syncthreads();
+    uint4 p0 = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t pmin0 = 0xffffffffu;
+    if (hq == 0 && __ballot(have0) != 0ull) {
+        if (have0) {
+            p0 = half_sum();
+            pmin0 = legal_min(ent0, p0);
+        }
+        uint32_t wm = pmin0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) wm = min(wm, (uint32_t)__shfl_xor((int)wm, o));
+        if (lane == 0) atomicMin(&u_min, wm);
+    }
+    round++;
+    __syncthreads();
+    // ... tier 1: within an eighth of the smallest partial SAD (and not beyond the probe's SAD: such a group is out for good) ...
+    const uint32_t ub0 = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
+    const uint32_t um = __builtin_amdgcn_readfirstlane(u_min);
+    const uint32_t t1 = um > 0xf0000000u ? um : um + (um >> 3) + 64u;
+    const bool keep1 = hq == 0 && have0 && pmin0 <= t1 && pmin0 <= ub0;
+    if (hq == 0) keep_append(keep1, ent0, p0);
+    __syncthreads();
+    const int nk1 = surv_n;
+    lower_rounds(0, nk1);
+    __syncthreads();
+    // ... tier 2: what else of the batch is still under the best SAD
+    const uint32_t best1 = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
+    const bool keep2 = hq == 0 && have0 && !keep1 && pmin0 <= best1;
+    if (hq == 0) keep_append(keep2, ent0, p0);
+    __syncthreads();
+    const int nk2 = surv_n;
+    lower_rounds(nk1, nk2);
     __syncthreads();
 
     const long long t_pass0 = kStats ? clock64() : 0;
     // ---- pass 1, only if some group left over has a bound <= the best SAD so far ----
     int n1 = 0;
     [[maybe_unused]] int n_kept = 0;  // (statistics) groups of the second pass that outlived their upper half
-    const uint32_t best_sad = (uint32_t)(best_key >> 32);
+    const unsigned long long bk0 = best_key;
+    const uint32_t best_sad = (uint32_t)(bk0 >> 32), best_idx = (uint32_t)bk0;
     if (rest_min != kNone && (rest_min << 4) <= best_sad) {
         // one sweep: a thread takes 8 consecutive bounds (one 16-byte load, all of a CTU's loads in flight at
         // once), a wave scan ranks the takers, ONE LDS atomic per wave reserves their slots
@@ -827,7 +883,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
 #pragma unroll
             for (int e = 0; e < 8; e++) {
                 const uint32_t v = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-                if (8 * vi + e < L.ngroups && v != kNone && (v << 4) <= best_sad) tm |= 1u << e;
+                if (8 * vi + e < L.ngroups && v != kNone && (v << 4) <= best_sad) {
+                    bool take = true;
+                    if ((v << 4) == best_sad) {  // can only tie: matters if it comes first in raster order
+                        const int gi = 8 * vi + e, dyi = gi / L.ngx, gx = gi - dyi * L.ngx;
+                        const int dx = max(L.wx0 - cx + 4 * gx, L.dxlo);
+                        take = (uint32_t)((L.dylo + dyi + R) * span + dx + R) < best_idx;
+                    }
+                    if (take) tm |= 1u << e;
+                }
             }
             const int cnt = __popc(tm);
             int inc = cnt;
@@ -845,102 +909,44 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             for (int e = 0; e < 8; e++)
                 if (tm & (1u << e)) list[slot++] = (uint16_t)(8 * vi + e);
         }
+        if (tid == 0) surv_n = 0;
         __syncthreads();
         n1 = list_n;
-        if constexpr (WAVES != 16) {
-            for (int base = 0; base < n1; base += kRound) {
-                const int li = base + set * 64 + lane;
-                const bool have = li < n1;
-                run_round((int)list[have ? li : 0], have);
-            }
-        } else {
-            // half rounds (see half_partial): upper halves over the schedule, the groups that stay under the best SAD
-            // of the first batch are kept; whenever the kept list could not take another half round's worth -- and at
-            // the end -- lower halves over the kept groups finish them.  One loop, one copy of the row code.
-            constexpr int kHalf = 2 * kRound;           // groups of a half round
-            const int hset = wave >> 1, hq = wave & 1;  // 64 groups a set; the two quarters of a half
-            if (tid == 0) surv_n = 0;
+        // upper halves over the schedule, the groups that stay under the best SAD are kept; whenever the kept list
+        // could not take another half round's worth -- and at the end -- lower halves over the kept groups finish
+        // them.  One loop, one copy of the row code.
+        int base = 0;
+        while (base < n1) {
+            // the threshold follows the search: every lower-half round may have brought a better SAD
+            const uint32_t cur_best = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
+            const int li = base + hset * 64 + lane;
+            const bool have = li < n1;
+            const int ent = have ? (int)list[li] : 0;
+            half_partial(ent, have, (B / 4) * hq);
             __syncthreads();
-            int base = 0, kbase = 0, nk = 0;
-            bool lower = false;
-            for (;;) {
-                // the threshold follows the search: every lower-half round may have brought a better SAD
-                const uint32_t cur_best = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
-                if (!lower) {
-                    const int kept = surv_n;  // uniform: read between barriers
-                    // finish what is kept as soon as it fills half a round (a better best SAD prunes what follows), when
-                    // the list could not take another half round's worth, and at the end
-                    if (base >= n1 || kept >= kHalf / 2 || kept + kHalf > surv_cap) {
-                        lower = true;
-                        nk = kept;
-                        kbase = 0;
-                        if constexpr (kStats) n_kept += kept;
-                    }
+            if (hq == 0 && __ballot(have) != 0ull) {
+                uint4 sm = make_uint4(0u, 0u, 0u, 0u);
+                bool keep = false;
+                if (have) {
+                    sm = half_sum();
+                    keep = legal_min(ent, sm) <= cur_best;
                 }
-                if (lower && kbase >= nk) {
-                    if (base >= n1) break;
-                    if (tid == 0) surv_n = 0;  // the kept groups are finished: collect again
-                    __syncthreads();
-                    lower = false;
-                    continue;
-                }
-                const int li = (lower ? kbase : base) + hset * 64 + lane;
-                const bool have = li < (lower ? nk : n1);
-                const int ent = have ? (int)(lower ? surv_ent[li] : list[li]) : 0;
-                half_partial(ent, have, (lower ? B / 2 : 0) + (B / 4) * hq);
+                keep_append(keep, ent, sm);
+            }
+            round++;
+            base += kHalf;
+            __syncthreads();  // surv_n and the kept entries are visible; part[] may be written again
+            const int kept = surv_n;
+            // finish what is kept as soon as it fills half a round (a better best SAD prunes what follows), when
+            // the list could not take another half round's worth, and at the end
+            if (base >= n1 || kept >= kHalf / 2 || kept + kHalf > surv_cap) {
+                if constexpr (kStats) n_kept += kept;
+                lower_rounds(0, kept);
+                __syncthreads();  // every wave is done with the kept list; best_key is visible
+                if (tid == 0) surv_n = 0;
                 __syncthreads();
-                if (hq == 0 && __ballot(have) != 0ull) {
-                    unsigned long long k = ~0ull;
-                    bool keep = false;
-                    uint4 sm = make_uint4(0u, 0u, 0u, 0u);
-                    if (have) {
-                        const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx, dy = L.dylo + dyi;
-                        sm = half_sum();
-                        if (lower) {
-                            const uint4 up = *reinterpret_cast<const uint4 *>(&surv_sum[4 * li]);
-                            sm = make_uint4(sm.x + up.x, sm.y + up.y, sm.z + up.z, sm.w + up.w);
-                        }
-                        const uint32_t sad[4] = {sm.x, sm.y, sm.z, sm.w};
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const int dx = L.wx0 - cx + 4 * gx + q;
-                            if (dx >= L.dxlo && dx <= L.dxhi) {
-                                const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
-                                k = key < k ? key : k;
-                                keep = keep || sad[q] <= cur_best;
-                            }
-                        }
-                    }
-                    if (lower) {  // wave-uniform
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) {
-                            const unsigned long long other = __shfl_xor(k, o);
-                            k = other < k ? other : k;
-                        }
-                        if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
-                    } else {
-                        const unsigned long long km = __ballot(keep);
-                        if (km != 0ull) {
-                            int wbase = 0;
-                            if (lane == 0) wbase = atomicAdd(&surv_n, __popcll(km));
-                            wbase = __shfl(wbase, 0);
-                            if (keep) {
-                                const int slot = wbase + __popcll(km & ((1ull << lane) - 1ull));
-                                surv_ent[slot] = (uint16_t)ent;
-                                *reinterpret_cast<uint4 *>(&surv_sum[4 * slot]) = sm;
-                            }
-                        }
-                    }
-                }
-                round++;
-                if (lower)
-                    kbase += kHalf;
-                else
-                    base += kHalf;
-                __syncthreads();  // surv_n and the kept entries are visible; part[] may be written again
             }
         }
-        __syncthreads();
     }
     if (tid == 0) {
         const unsigned long long best = best_key;
@@ -960,15 +966,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             stats[16 * ctu_id + 5] = (uint32_t)t_begin;               // absolute, low 32 bits
             stats[16 * ctu_id + 6] = (uint32_t)t_end;
             stats[16 * ctu_id + 8] = h.est;
-            stats[16 * ctu_id + 14] = (uint32_t)n_kept;
+            stats[16 * ctu_id + 14] = (uint32_t)n_kept;               // lower halves of the second pass
+            stats[16 * ctu_id + 15] = (uint32_t)nk2;                  // lower halves of the first batch (tier 1 + tier 2)
             stats[16 * ctu_id + 9] = (uint32_t)blockIdx.x;
             stats[16 * ctu_id + 7] = (__builtin_amdgcn_s_getreg(63492) & 0xffffu) | (__builtin_amdgcn_s_getreg(6164) << 16);  // HW_ID | XCC_ID
         }
         if (!reserve) {  // a heavy CTU: ask only now that it is done
             it_next = (int)atomicAdd(&ctrl[kClasses], 1u);
-            ctu_next_v = item_ctu(it_next < total ? it_next : 0);
+            ctu_next_v = item_ctu(it_next < nitems ? it_next : 0);
         }
-        next_ctu = it_next < total ? (int)ctu_next_v : -1;
+        next_ctu = it_next < nitems ? (int)ctu_next_v : -1;
         it_now = it_next;
     }
     __syncthreads();  // the window and part[] are free again; next_ctu is visible
@@ -1107,7 +1114,7 @@ template <int WAVES, int B>
 static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8_t *d_cur, const uint8_t *d_ref,
                         const uint16_t *gl, const uint16_t *list0, uint16_t *wg_list, const SeaHdr *hdr,
                         const uint32_t *order, uint32_t *ctrl, int total, x265amd_mv *d_out, const MeGeom &g, int gl_pitch,
-                        int win_dwords, int surv_cap)
+                        int win_dwords, int surv_off, int surv_cap)
 {
     uint32_t *const stats = g_me_stats;  // read once: the variant and its argument must agree
     const void *fn = stats ? (const void *)sea_exact_kernel<true, WAVES, B> : (const void *)sea_exact_kernel<false, WAVES, B>;
@@ -1120,10 +1127,10 @@ static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8
     const dim3 grid((unsigned)(total < resident ? total : resident));
     if (stats)
         hipLaunchKernelGGL((sea_exact_kernel<true, WAVES, B>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
-                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, surv_cap, stats);
+                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, surv_off, surv_cap, stats);
     else
         hipLaunchKernelGGL((sea_exact_kernel<false, WAVES, B>), grid, dim3(WAVES * 64), lds, st, d_cur, d_ref, gl, list0, wg_list,
-                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, surv_cap, stats);
+                           hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, surv_off, surv_cap, stats);
     return X265AMD_OK;
 }
 
@@ -1152,9 +1159,11 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     if (max_groups > 0xffff || max_ndy > (ctu / 4) * sea_max_chain(ctu / 4)) return X265AMD_ERR_LDS;  // 16-bit schedule entries
     const int win_dwords = max_rows * max_pitch;
     const size_t list_bytes = ((size_t)max_groups * 2 + 15) & ~(size_t)15;
-    // 8-wave workgroups (window + schedule in LDS, 16 KB of partial sums) when two of them fit a CU;
-    // otherwise ONE 16-wave workgroup per CU (window only + 32 KB of partial sums, schedule in the workspace)
-    const size_t lds8 = (size_t)win_dwords * 4 + list_bytes + (size_t)g_sea_lds_pad;
+    // 8-wave workgroups (window + schedule + kept list in LDS, 16 KB of partial sums) when two of them fit a CU;
+    // otherwise ONE 16-wave workgroup per CU (window + kept list, 32 KB of partial sums, schedule in the workspace)
+    constexpr int kSurv8 = 512;  // kept groups of an 8-wave workgroup: two half rounds' worth, 18 bytes each
+    const size_t surv8_off = (((size_t)win_dwords * 4 + list_bytes + 15) & ~(size_t)15);
+    const size_t lds8 = surv8_off + (size_t)kSurv8 * 18 + (size_t)g_sea_lds_pad;
     size_t lds16 = (size_t)win_dwords * 4;
     const size_t lds_cap = (size_t)ds.lds_limit;
     bool waves16 = 2 * (lds8 + 17408) > lds_cap;
@@ -1226,7 +1235,8 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;
 #define X265AMD_EXACT(WV, BB, LDS) \
-    launch_exact<WV, BB>(ds, LDS, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, surv_cap)
+    launch_exact<WV, BB>(ds, LDS, st, d_cur, d_ref, gl, list0, wg_list, hdr, order, ctrl, total, d_out, g, gl_pitch, win_dwords, \
+                         waves16 ? (int)(((size_t)win_dwords + 3) & ~(size_t)3) : (int)(surv8_off / 4), waves16 ? surv_cap : kSurv8)
     if (ctu == 64)
         status = waves16 ? X265AMD_EXACT(16, 64, lds16) : X265AMD_EXACT(8, 64, lds8);
     else
