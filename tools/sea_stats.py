@@ -25,6 +25,8 @@ names = ["n_pass0", "n_pass1", "cyc_stage", "cyc_pass0", "cyc_pass1"]
 bnames = {10: "b_cyc_csum", 11: "b_cyc_bounds", 12: "b_cyc_scan", 13: "b_cyc_write"}
 for i, n in enumerate(names):
     print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
+print(f"{'low_pass0':14s} mean {s[:, 15].mean():10.1f}  median {np.median(s[:, 15]):10.1f}  max {s[:, 15].max():10d}   (lower halves finished of the first batch)")
+print(f"{'low_pass1':14s} mean {s[:, 14].mean():10.1f}  median {np.median(s[:, 14]):10.1f}  max {s[:, 14].max():10d}   (lower halves finished of the second pass)")
 for i, n in bnames.items():
     print(f"{n:14s} mean {s[:, i].mean():10.1f}  median {np.median(s[:, i]):10.1f}  max {s[:, i].max():10d}")
 interior = [i for i in range(nctu_all) if 2 <= (i % nctu) % (W // 64) <= W // 64 - 3 and 2 <= (i % nctu) // (W // 64) <= H // 64 - 3]

@@ -21,6 +21,8 @@
 //                       batch, then of everything whose bound is still <= best.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "me_common.h"
 
@@ -545,10 +547,10 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     }
 }
 
-// One wave's part of a half round of kernel 2: the B / 4 block rows from `row0` on (wave-uniform) of the lanes' groups
+// One wave's part of a (half) round of kernel 2: the RQ block rows from `row0` on (wave-uniform) of the lanes' groups
 // (`ent` = dyi * ngx + gx, valid where `have`): partial SADs of the four members to `dst` (the lane's 16 bytes of part[]).
 // The current rows are wave-uniform: s_load into SGPRs, the scalar operand of v_qsad_pk_u16_u8.
-template <int B>
+template <int B, int RQ>
 __device__ __forceinline__ void sea_half_partial(const uint32_t *__restrict__ win, int pitch, int ngx,
                                                  const uint32_t *__restrict__ cbase, int cstr, uint32_t *__restrict__ dst,
                                                  int ent, bool have, int row0)
@@ -556,7 +558,8 @@ __device__ __forceinline__ void sea_half_partial(const uint32_t *__restrict__ wi
     if (__ballot(have) == 0ull) return;  // wave-uniform
     ent = have ? ent : 0;
     const int dyi = ent / ngx, gx = ent - dyi * ngx;
-    constexpr int RQ = B / 4, NW = B / 4;  // rows of a quarter of the block, dwords of a block row
+    constexpr int NW = B / 4;  // dwords of a block row; RQ = rows taken (even)
+    static_assert(RQ % 2 == 0, "two-row pipeline");
     const uint32_t *wrow = win + (dyi + row0) * pitch + gx;
     const uint32_t *crow = cbase + row0 * cstr;
     uint32_t acc32[4] = {0u, 0u, 0u, 0u};
@@ -591,6 +594,10 @@ __device__ __forceinline__ void sea_half_partial(const uint32_t *__restrict__ wi
             for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
             acc16 = 0;
         }
+    }
+    if constexpr (RQ % 4 != 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc32[q] += (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
     }
 #undef SEA_LOAD
 #undef SEA_ROW
@@ -755,7 +762,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
 
     // this wave's part of a half round (sea_half_partial): the B / 4 rows from `row0` on of the lanes' groups
     auto half_partial = [&](int ent, bool have, int row0) __attribute__((always_inline)) {
-        sea_half_partial<B>(win, L.pitch, L.ngx, cbase, cstr, part[round & 1] + (wave * 64 + lane) * 4, ent, have, row0);
+        sea_half_partial<B, B / 4>(win, L.pitch, L.ngx, cbase, cstr, part[round & 1] + (wave * 64 + lane) * 4, ent, have, row0);
     };
     // the two quarters of a half that the waves `wave` and `wave + 1` left in part[]
     auto half_sum = [&]() __attribute__((always_inline)) -> uint4 {
@@ -827,6 +834,55 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         }
     };
 
+    // ---- at most 64 groups: one set of lanes, so the ROWS are split over eight waves instead -- a wave takes an
+    //      eighth of them, wave 0 adds the eight partial sums up.  Same arithmetic, a quarter (lower halves) or half
+    //      (whole blocks) of the latency of a half round in which six of eight waves would stand by.
+    //      kLower: the lower halves of kept groups (surv_ent[from .. to), + their upper-half SADs);
+    //      else whole blocks of schedule entries list[from .. to). ----
+    auto split_round = [&](auto lower_c, int from, int to) __attribute__((always_inline)) {
+        constexpr bool kLower = decltype(lower_c)::value;
+        constexpr int NR = kLower ? B / 16 : B / 8;  // rows per wave
+        const int li = from + lane;
+        const bool have = li < to;
+        const int ent = have ? (int)(kLower ? surv_ent[li] : list[li]) : 0;
+        if (wave < 8)
+            sea_half_partial<B, NR>(win, L.pitch, L.ngx, cbase, cstr, part[round & 1] + (wave * 64 + lane) * 4, ent, have,
+                                    (kLower ? B / 2 : 0) + NR * wave);
+        __syncthreads();
+        if (wave == 0) {
+            unsigned long long k = ~0ull;
+            if (have) {
+                const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx, dy = L.dylo + dyi;
+                uint4 sm = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (kLower) sm = *reinterpret_cast<const uint4 *>(&surv_sum[4 * li]);
+                const uint32_t *pbuf = part[round & 1];
+#pragma unroll
+                for (int w8 = 0; w8 < 8; w8++) {
+                    const uint4 t = *reinterpret_cast<const uint4 *>(&pbuf[(w8 * 64 + lane) * 4]);
+                    sm = make_uint4(sm.x + t.x, sm.y + t.y, sm.z + t.z, sm.w + t.w);
+                }
+                const uint32_t sad[4] = {sm.x, sm.y, sm.z, sm.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int dx = L.wx0 - cx + 4 * gx + q;
+                    if (dx >= L.dxlo && dx <= L.dxhi) {
+                        const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
+                        k = key < k ? key : k;
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long other = __shfl_xor(k, o);
+                k = other < k ? other : k;
+            }
+            if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
+        }
+        round++;
+    };
+    using SeaLowerHalves = std::integral_constant<bool, true>;
+    using SeaWholeBlocks = std::integral_constant<bool, false>;
+
     // ---- pass 0: the first batch.  Upper halves of all of it ... ----
     const bool have0 = slot0 < n0;
     half_partial(ent0, have0, (B / 4) * hq);
@@ -845,24 +901,28 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     }
     round++;
     __syncthreads();
-    // ... tier 1: within an eighth of the smallest partial SAD (and not beyond the probe's SAD: such a group is out for good) ...
-    const uint32_t ub0 = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
+    // ... then the lower halves, in two tiers.  Tier 1: within an eighth of the smallest partial SAD (and not beyond
+    // the probe's SAD: such a group is out for good); tier 2: what else of the batch is still under the best SAD.
     const uint32_t um = __builtin_amdgcn_readfirstlane(u_min);
     const uint32_t t1 = um > 0xf0000000u ? um : um + (um >> 3) + 64u;
-    const bool keep1 = hq == 0 && have0 && pmin0 <= t1 && pmin0 <= ub0;
-    if (hq == 0) keep_append(keep1, ent0, p0);
-    __syncthreads();
-    const int nk1 = surv_n;
-    lower_rounds(0, nk1);
-    __syncthreads();
-    // ... tier 2: what else of the batch is still under the best SAD
-    const uint32_t best1 = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
-    const bool keep2 = hq == 0 && have0 && !keep1 && pmin0 <= best1;
-    if (hq == 0) keep_append(keep2, ent0, p0);
-    __syncthreads();
-    const int nk2 = surv_n;
-    lower_rounds(nk1, nk2);
-    __syncthreads();
+    bool taken = false;
+    int nk2 = 0;
+#pragma unroll 1
+    for (int tier = 0; tier < 2; tier++) {
+        const uint32_t bsf = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
+        const uint32_t thr = tier == 0 ? min(t1, bsf) : bsf;
+        const bool keep = hq == 0 && have0 && !taken && pmin0 <= thr;
+        taken = taken || keep;
+        if (hq == 0) keep_append(keep, ent0, p0);
+        __syncthreads();
+        const int nk = surv_n;
+        if (nk - nk2 > 64)
+            lower_rounds(nk2, nk);
+        else if (nk > nk2)
+            split_round(SeaLowerHalves{}, nk2, nk);
+        nk2 = nk;
+        __syncthreads();
+    }
 
     const long long t_pass0 = kStats ? clock64() : 0;
     // ---- pass 1, only if some group left over has a bound <= the best SAD so far ----
@@ -914,8 +974,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         n1 = list_n;
         // upper halves over the schedule, the groups that stay under the best SAD are kept; whenever the kept list
         // could not take another half round's worth -- and at the end -- lower halves over the kept groups finish
-        // them.  One loop, one copy of the row code.
+        // them.  A schedule of one set of lanes goes through whole, its rows split over the waves.
         int base = 0;
+        if (n1 <= 64) {
+            split_round(SeaWholeBlocks{}, 0, n1);
+            base = n1;
+            if constexpr (kStats) n_kept += n1;
+            __syncthreads();
+        }
         while (base < n1) {
             // the threshold follows the search: every lower-half round may have brought a better SAD
             const uint32_t cur_best = __builtin_amdgcn_readfirstlane((uint32_t)(best_key >> 32));
@@ -941,7 +1007,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             // the list could not take another half round's worth, and at the end
             if (base >= n1 || kept >= kHalf / 2 || kept + kHalf > surv_cap) {
                 if constexpr (kStats) n_kept += kept;
-                lower_rounds(0, kept);
+                if (kept > 64)
+                    lower_rounds(0, kept);
+                else if (kept > 0)
+                    split_round(SeaLowerHalves{}, 0, kept);
                 __syncthreads();  // every wave is done with the kept list; best_key is visible
                 if (tid == 0) surv_n = 0;
                 __syncthreads();
