@@ -24,7 +24,7 @@ inline int hip_status(hipError_t e) { return e == hipSuccess ? X265AMD_OK : X265
 // per GPU, or several threads on one GPU, can therefore use the library side by side; the mutable parts
 // (the occupancy cache, the drop-in staging block) are guarded by state_mutex().
 constexpr int kMaxDevices = 64;
-constexpr int kOccSlots = 8;
+constexpr int kOccSlots = 16;
 
 struct OccEntry {  // occupancy of one kernel variant at one dynamic-LDS size
     const void *fn;

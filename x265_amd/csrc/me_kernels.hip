@@ -6,6 +6,7 @@
 // (src/encode.cpp:725-727,762-765).
 #include "common.h"
 #include "me_common.h"
+#include "me_qsad_body.h"
 
 namespace x265amd {
 
@@ -136,138 +137,21 @@ __global__ __launch_bounds__(256) void me_fullsearch_basic(const MeParams p)
 
 
 // ---------------------------------------------------------------------------
-// Exhaustive search for 64x64 CTUs, production kernel.
-//
-// v_qsad_pk_u16_u8 does the work: one instruction = the 4-pixel SADs of one
-// current-block dword against FOUR consecutive byte offsets of an 8-byte
-// reference span, accumulated into four u16 lanes -- 16 pixel-SADs per lane per
-// issue, and no alignment shuffles at all.  Measured on gfx950 it issues at
-// 16.5 cycles/wave (tools/ubench_valu), i.e. 1.03 cycles per pixel-SAD-lane,
-// the best the integer VALU offers (v_sad_u8: 4.3 cycles for 4).
-//
-// Decomposition: workgroup = one (CTU, ref, frame).  Only the candidates that
-// keep the block inside the picture are enumerated (border CTUs do less work).
-// A lane owns a 4 (dx) x T (dy) tile of candidates.  For every reference row rho
-// of its tile the lane reads the 16+1 window dwords it needs from LDS
-// (ds_read2_b32 pairs, exactly the 64-bit operands qsad wants) and applies them
-// to the T current rows rho, rho-1, .., rho-T+1.  The current rows are the same
-// for every lane, so they live in SGPRs (s_load_dwordx16) and enter qsad as the
-// scalar operand: zero VGPRs, zero LDS traffic for the current block.  The u16
-// partial sums are widened to u32 every 4 rows (64 * 1020 < 65536).
-// Winner = min over (sad << 32 | raster index) by wave shuffles.
+// Exhaustive search, production kernel: one workgroup per (block, ref, frame); the search itself is
+// me_qsad_block (me_qsad_body.h).
 // ---------------------------------------------------------------------------
 template <int B>  // block size: 64 (CTU), 32 or 16 (PU sizes); B / 4 dwords per row
 __global__ __launch_bounds__(256, 2) void me_fullsearch_qsad(const uint8_t *__restrict__ cur_base,
                                                              const uint8_t *__restrict__ ref_base,
                                                              x265amd_mv *__restrict__ out, const MeGeom g)
 {
-    constexpr int T = kMeT, DW = B / 4;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *win = smem;
-    const int tid = threadIdx.x;
     const int ctx = blockIdx.x, cty = blockIdx.y;
     const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
-    const int cx = ctx * B, cy = cty * B;
-    const int R = g.range;
-    int dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows;
-    me_qsad_layout(g.width, g.height, R, cx, cy, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows, B);
-    const uint8_t *cur = cur_base + f * g.cur_fs;
-    const uint8_t *ref = ref_base + f * g.ref_fs + rr * g.ref_rs;
-
-    // ---- stage the reference window: coalesced dword loads of 8-bit luma ----
-    for (int i = tid; i < win_rows * pitch; i += 256) {
-        const int wy = i / pitch, wq = i - wy * pitch;
-        const int gx = wx0 + 4 * wq, gy = cy + dylo + wy;
-        uint32_t v = 0;  // outside the picture: only ever paired with candidates that are masked below
-        if (gy < g.height && gx + 4 <= g.width) v = *reinterpret_cast<const uint32_t *>(ref + (int64_t)gy * g.stride + gx);
-        win[i] = v;
-    }
-    __syncthreads();
-
-    unsigned long long best = ~0ull;
-    const int ntask = ngx * ngy;
-    const int span = 2 * R + 1;
-    const uint32_t *__restrict__ cbase = reinterpret_cast<const uint32_t *>(cur + (int64_t)cy * g.stride + cx);
-    const int cstr = g.stride >> 2;
-    // whole waves iterate together (the current rows are wave-uniform scalar operands)
-    for (int task = tid; task < ((ntask + 63) & ~63); task += 256) {
-        const int tk = min(task, ntask - 1);
-        const int gy = tk / ngx, gx = tk - gy * ngx;
-        const uint32_t *wrow = win + (T * gy) * pitch + gx;
-        uint64_t acc16[T];
-        uint32_t acc32[T][4];
-#pragma unroll
-        for (int t = 0; t < T; t++) {
-            acc16[t] = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) acc32[t][j] = 0;
-        }
-        uint32_t S[T][DW];  // sliding window of T current rows, SGPRs
-#pragma unroll 1  // one T-row step per trip: unrolled further the 32x32 instance spills
-        for (int m = 0; m < (B + T - 1 + T - 1) / T; m++) {
-#pragma unroll
-            for (int j = 0; j < T; j++) {
-                const int rho = T * m + j;  // reference row of the tile == newest current row
-                if (rho < B) {
-#pragma unroll
-                    for (int k = 0; k < DW; k++) S[j][k] = cbase[rho * cstr + k];
-                }
-                if (rho < B + T - 1) {
-                    const uint32_t *p = wrow + rho * pitch;
-                    uint64_t pr[DW];
-#pragma unroll
-                    for (int k = 0; k < DW; k++) pr[k] = ((uint64_t)p[k + 1] << 32) | p[k];
-#pragma unroll
-                    for (int t = 0; t < T; t++) {
-                        const int r = rho - t;  // current row paired with this reference row for dy offset t
-                        if (r >= 0 && r < B) {
-                            const int sj = (j - t + T) % T;
-#pragma unroll
-                            for (int k = 0; k < DW; k++)
-                                acc16[t] = __builtin_amdgcn_qsad_pk_u16_u8(pr[k], S[sj][k], acc16[t]);
-                            if ((r & 3) == 3) {  // 4 rows * B/4 qsads * 1020 < 2^16: widen before it can wrap
-#pragma unroll
-                                for (int q = 0; q < 4; q++) acc32[t][q] += (uint32_t)(acc16[t] >> (16 * q)) & 0xffffu;
-                                acc16[t] = 0;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        if (task < ntask) {
-#pragma unroll
-            for (int t = 0; t < T; t++) {
-                const int dy = dylo + T * gy + t;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int dx = wx0 - cx + 4 * gx + q;
-                    if (dy <= dyhi && dx >= dxlo && dx <= dxhi) {
-                        const unsigned long long key =
-                            ((unsigned long long)acc32[t][q] << 32) | (unsigned)((dy + R) * span + dx + R);
-                        best = key < best ? key : best;
-                    }
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(best, o);
-        best = other < best ? other : best;
-    }
-    __shared__ unsigned long long wbest[4];
-    if ((tid & 63) == 0) wbest[tid >> 6] = best;
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < 4; w++) best = wbest[w] < best ? wbest[w] : best;
-        x265amd_mv mv;
-        const int c = (int)(best & 0xffffffffu);
-        mv.mvx = (int16_t)(c % span - R);
-        mv.mvy = (int16_t)(c / span - R);
-        mv.sad = (uint32_t)(best >> 32);
-        out[((int64_t)f * g.nrefs + rr) * g.ctus_x * g.ctus_y + cty * g.ctus_x + ctx] = mv;
-    }
+    const unsigned long long best = me_qsad_block<B>(smem, cur_base + f * g.cur_fs, ref_base + f * g.ref_fs + rr * g.ref_rs, g,
+                                                     ctx * B, cty * B, 0, 1);
+    if (threadIdx.x == 0)
+        out[((int64_t)f * g.nrefs + rr) * g.ctus_x * g.ctus_y + cty * g.ctus_x + ctx] = me_key_to_mv(best, g.range);
 }
 
 // x265amd_init, once per device: every search kernel may use the device's whole LDS from then on

@@ -25,6 +25,7 @@
 
 #include "common.h"
 #include "me_common.h"
+#include "me_qsad_body.h"
 
 namespace x265amd {
 
@@ -171,7 +172,10 @@ struct SeaHdr {  // per (plane, CTU)
 };
 constexpr int kFirst = 256;   // first batch: two rounds of 128 groups
 constexpr int kMaxWgLists = 512;  // persistent workgroups that may need a schedule slice in the workspace
-constexpr int kClasses = 4;   // launch-order classes (kClasses + 1 <= 8 counters: box16_pairs zeroes 8) of the work estimate, heaviest first
+constexpr int kClasses = 4;   // launch-order classes of the work estimate, heaviest first
+// ctrl[] (8 counters, zeroed by box16_pairs): [0 .. kClasses) lengths of the class queues, [kClasses] next item of kernel 2,
+// [kClasses + 1] length of the every-candidate list
+static_assert(kClasses + 2 <= 8, "box16_pairs zeroes 8 counters");
 __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est >= 1024 ? 1 : est >= 850 ? 2 : 3; }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     __shared__ uint32_t hist[kBins];
     __shared__ uint32_t csum[16];
     __shared__ int list_n, eq_n, pick_bin, below_n, est_n;
-    __shared__ uint32_t min_key, probe_sad, probe_idx, pref[kBins];
+    __shared__ uint32_t min_key, max_st, probe_sad, probe_idx, pref[kBins];
     __shared__ uint32_t rest_lb;
     __shared__ uint32_t bank_cnt[32];
     __shared__ uint16_t sel_ent[kFirst];
@@ -225,6 +229,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         list_n = 0;
         eq_n = 0;
         min_key = 0xffffffffu;
+        max_st = 0;
         rest_lb = kNone;
     }
     // ---- the block's sub-block sums: S lanes per sub-block, one S-pixel row each ----
@@ -251,6 +256,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     const int a = cx + L.dxlo - L.wx0;  // window column of dxlo
     const int ndx = L.dxhi - L.dxlo + 1;
     uint32_t my_min = 0xffffffffu;  // (stored bound << 16 | group) of the lane's best group
+    uint32_t my_max = 0;            // largest stored bound of the lane's groups
     {
         const int nchain = S * L.ngx;  // (c, gx)
         // whole sweeps of chains; a short remainder (the 33rd column of groups of a +-64 window: 16 of
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
                     if (st != kNone) {
                         atomicAdd(&hist[lb_bin(st)], 1u);
                         my_min = min(my_min, (st << 16) | (uint32_t)(dyi * L.ngx + gx));
+                        my_max = max(my_max, st);
                     }
                 }
         }
@@ -344,12 +351,18 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             if (st != kNone) {
                 atomicAdd(&hist[lb_bin(st)], 1u);
                 my_min = min(my_min, (st << 16) | (uint32_t)(dyi * L.ngx + gx));
+                my_max = max(my_max, st);
             }
         }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, o));
-    if (lane == 0 && my_min != 0xffffffffu) atomicMin(&min_key, my_min);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o));
+    if (lane == 0 && my_min != 0xffffffffu) {
+        atomicMin(&min_key, my_min);
+        atomicMax(&max_st, my_max);
+    }
     __syncthreads();
 
     const long long tb2 = stats ? clock64() : 0;
@@ -396,6 +409,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     uint16_t *glo = gl + ctu_id * gl_pitch;
     uint16_t *lo = list0 + ctu_id * gl_pitch;
     uint32_t rest_min = kNone;
+    int n0 = 0;
     const int nvec = (L.ngroups + 7) >> 3;
     const int wtid = tid < 64 ? tid : tid - 64;  // wave 1 sits the write-out out: it runs the probe meanwhile
     if (tid >= 64 && tid < 128) {
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     //      (dyi + row) * pitch + gx + k, so the 32 lanes of a half wave collide whenever their
     //      dyi * pitch + gx agree mod 32.  Deal the entries out bank by bank (rank within the bank first,
     //      then bank): any 32 consecutive slots then hold at most two entries of one bank. ----
-    const int n0 = pb == kBins ? list_n : nbelow + min(quota, eq_n);
+    n0 = pb == kBins ? list_n : nbelow + min(quota, eq_n);
     int my_ent = 0, my_bank = 0, my_rank = 0;
     if (tid < n0) {
         my_ent = sel_ent[tid];
@@ -527,6 +541,11 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     }
     if (tid == 0) {
         const uint32_t ub = probe_sad;  // published by the barriers since
+        // A block on which the bounds are useless by a wide margin -- even the largest is under a quarter of the probe's
+        // SAD: noise, grain -- costs the elimination search more than every candidate's SAD costs the plain kernel: it
+        // goes on the list of kernel 3.  Not when the probe found a perfect match (flat content: ties in raster order
+        // end that search after the first batch).
+        const bool route = ub != 0xffffffffu && ub > 0u && pref[kBins - 1] >= 64u && (max_st << 6) <= ub;
         const uint32_t ubs = ub == 0xffffffffu ? 0u : min(ub >> 4, 0xfffeu);  // same units as the stored bounds
         est_n = (int)pref[min(lb_bin(ubs), kBins - 1)];
         SeaHdr h;
@@ -542,8 +561,15 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             stats[16 * ctu_id + 12] = (uint32_t)(tb3 - tb2);        //         histogram scan
             stats[16 * ctu_id + 13] = (uint32_t)(clock64() - tb3);  //         write-out
         }
-        const int cls = sea_class(est_n);
-        order[(size_t)cls * (uint32_t)total + atomicAdd(&ctrl[cls], 1u)] = (uint32_t)ctu_id;
+        if (route) {
+            unsigned long long *bk = reinterpret_cast<unsigned long long *>(glo);  // the block's row of bounds is free: merge key + count
+            bk[0] = ~0ull;
+            reinterpret_cast<uint32_t *>(glo)[2] = 0u;
+            order[(size_t)kClasses * (uint32_t)total + atomicAdd(&ctrl[kClasses + 1], 1u)] = (uint32_t)ctu_id;
+        } else {
+            const int cls = sea_class(est_n);
+            order[(size_t)cls * (uint32_t)total + atomicAdd(&ctrl[cls], 1u)] = (uint32_t)ctu_id;
+        }
     }
 }
 
@@ -1053,6 +1079,45 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel 3: every candidate's SAD (me_qsad_block, the search of x265amd_me_fullsearch) for the blocks kernel 1 put
+// on its list.  One workgroup per (block, slice) item; the grid is sized for the case that EVERY block is listed, and
+// a workgroup beyond the items exits at once (all of them, when the list is empty).  A short list is cut into slices
+// of candidate rows, as many as the grid has room for (at most 8); slices of a block meet in a 64-bit atomic minimum
+// on the key (in the block's own, otherwise unused, row of bounds) and the last one to arrive writes the vector out.
+// ---------------------------------------------------------------------------------------------
+template <int B>
+__global__ __launch_bounds__(256, 2) void me_list_qsad(const uint8_t *__restrict__ cur_base, const uint8_t *__restrict__ ref_base,
+                                                       x265amd_mv *__restrict__ out, const MeGeom g,
+                                                       const uint32_t *__restrict__ blist, const uint32_t *__restrict__ ctrl,
+                                                       uint16_t *__restrict__ gl, int gl_pitch)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int n = (int)ctrl[kClasses + 1];
+    if (n == 0) return;  // grid-uniform
+    const int nsl = min((int)gridDim.x / n, 8);  // >= 1: the grid has a workgroup per block
+    const int item = blockIdx.x;
+    if (item >= n * nsl) return;  // block-uniform
+    const int ctu = (int)blist[item / nsl], slice = item % nsl;
+    const int per_plane = g.ctus_x * g.ctus_y;
+    const int plane = ctu / per_plane, cin = ctu - plane * per_plane;
+    const int cty = cin / g.ctus_x, ctx = cin - cty * g.ctus_x;
+    const int f = plane / g.nrefs, rr = plane - f * g.nrefs;
+    const unsigned long long best = me_qsad_block<B>(smem, cur_base + f * g.cur_fs, ref_base + f * g.ref_fs + rr * g.ref_rs, g,
+                                                     ctx * B, cty * B, slice, nsl);
+    if (threadIdx.x == 0) {
+        if (nsl == 1) {
+            out[ctu] = me_key_to_mv(best, g.range);
+        } else {
+            unsigned long long *bk = reinterpret_cast<unsigned long long *>(gl + (size_t)ctu * gl_pitch);
+            atomicMin(bk, best);
+            __threadfence();
+            if (atomicAdd(reinterpret_cast<uint32_t *>(bk) + 2, 1u) == (uint32_t)(nsl - 1))  // the last slice of the block
+                out[ctu] = me_key_to_mv(atomicMin(bk, ~0ull), g.range);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Static scratch for x265amd_me_fullsearch_sea_static: the workspace of the search (pair plane, bounds,
 // first-batch lists, headers, queues, second-pass schedules) for callers that cannot allocate.  Every GPU
 // the library runs on holds its own copy of this array, at its own address, until the process ends;
@@ -1069,7 +1134,7 @@ int me_sea_device_setup(DeviceState &ds)
                          (const void *)sea_exact_kernel<true, 16, 64>,
                          (const void *)sea_bounds_kernel<32>, (const void *)sea_exact_kernel<false, 8, 32>,
                          (const void *)sea_exact_kernel<true, 8, 32>, (const void *)sea_exact_kernel<false, 16, 32>,
-                         (const void *)sea_exact_kernel<true, 16, 32>};
+                         (const void *)sea_exact_kernel<true, 16, 32>, (const void *)me_list_qsad<64>, (const void *)me_list_qsad<32>};
     for (const void *fn : fns) {
         const int st = allow_full_lds(fn, ds);
         if (st != X265AMD_OK) return st;
@@ -1148,7 +1213,7 @@ extern "C" size_t x265amd_me_workspace_bytes_ctu(int width, int height, int ctu,
     return align256(4 * (size_t)width * height * planes)                    // pair plane (u32) per (frame, ref) plane
            + 2 * align256(sizeof(uint16_t) * per_ctu * nctu * planes)      // bounds + first-batch list per CTU
            + align256(sizeof(SeaHdr) * nctu * planes)
-           + align256(sizeof(uint32_t) * kClasses * nctu * planes)         // launch-order queues of the exact kernel
+           + align256(sizeof(uint32_t) * (kClasses + 1) * nctu * planes)   // launch-order queues of the exact kernel + the every-candidate list
            + 256                                                           // their counters
            + align256(sizeof(uint16_t) * per_ctu * kMaxWgLists);           // second-pass schedules of 16-wave workgroups
 }
@@ -1265,8 +1330,8 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     SeaHdr *hdr = (SeaHdr *)ws;
     ws += align256(sizeof(SeaHdr) * nctu * (size_t)nplanes);
     uint32_t *order = (uint32_t *)ws;
-    ws += align256(sizeof(uint32_t) * kClasses * nctu * (size_t)nplanes);
-    uint32_t *ctrl = (uint32_t *)ws;  // [0..kClasses) queue lengths, [kClasses] next item to hand out
+    ws += align256(sizeof(uint32_t) * (kClasses + 1) * nctu * (size_t)nplanes);
+    uint32_t *ctrl = (uint32_t *)ws;  // queue lengths and hand-out counters (see kClasses)
     if ((int64_t)nctu * nplanes > 0x7fffffff) return X265AMD_ERR_ARG;
     const int total = (int)(nctu * (size_t)nplanes);
 
@@ -1312,6 +1377,26 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
         status = waves16 ? X265AMD_EXACT(16, 32, lds16) : X265AMD_EXACT(8, 32, lds8);
 #undef X265AMD_EXACT
     if (status != X265AMD_OK) return status;
+    {
+        // kernel 3: a workgroup per block, of which those beyond the every-candidate list exit at once (usually all)
+        int mr = 0, mp = 0, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows;
+        for (int cy = 0; cy < height; cy += ctu) {
+            me_qsad_layout(width, height, range, 0, cy, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows, ctu);
+            mr = win_rows > mr ? win_rows : mr;
+        }
+        for (int cx = 0; cx < width; cx += ctu) {
+            me_qsad_layout(width, height, range, cx, 0, dylo, dyhi, dxlo, dxhi, wx0, ngx, ngy, pitch, win_rows, ctu);
+            mp = pitch > mp ? pitch : mp;
+        }
+        const size_t lds3 = (size_t)mr * mp * 4;
+        if (lds3 + 128 > lds_cap) return X265AMD_ERR_LDS;
+        const dim3 grid3((unsigned)total);
+        const uint32_t *blist = order + (size_t)kClasses * total;
+        if (ctu == 64)
+            hipLaunchKernelGGL(me_list_qsad<64>, grid3, dim3(256), lds3, st, d_cur, d_ref, d_out, g, blist, ctrl, gl, gl_pitch);
+        else
+            hipLaunchKernelGGL(me_list_qsad<32>, grid3, dim3(256), lds3, st, d_cur, d_ref, d_out, g, blist, ctrl, gl, gl_pitch);
+    }
     if (timing) (void)hipEventRecord(g_me_ev[4], st);
     return hip_status(hipGetLastError());
 }
