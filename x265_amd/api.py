@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libx265amd.so")
+LIB_PATH = os.environ.get("X265AMD_LIB_PATH") or os.path.join(_HERE, "lib", "libx265amd.so")  # the override: A/B runs of tools/
 
 MODE_INVALID = 255            # inc/x265.h:70
 SLICE_I, SLICE_P, SLICE_B = 0, 1, 2   # inc/x265.h:39-43

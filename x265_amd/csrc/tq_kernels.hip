@@ -389,6 +389,13 @@ static void quant_constants(int tu, int qp, int slice_type, TqParams &p)
     p.dq_shift = 20 - 14 - tshift;              // QUANT_IQUANT_SHIFT - QUANT_SHIFT - tshift
     p.dq_rnd = 1 << (p.dq_shift - 1);
     p.dq_scale = kInvQuantScales[qp % 6] << (qp / 6);
+    if (qp / 6 >= p.dq_shift) {
+        // level * (IQ << qp/6) is a multiple of 2^shift then: the rounding term falls out under the floor, and
+        // (level * scale + rnd) >> shift = level * (IQ << (qp/6 - shift)) exactly, either sign
+        p.dq_scale = kInvQuantScales[qp % 6] << (qp / 6 - p.dq_shift);
+        p.dq_rnd = 0;
+        p.dq_shift = 0;
+    }
 }
 
 // debugging aid (include/x265_amd_debug.h): 0 = the library's choice, 1 = always the butterfly kernel

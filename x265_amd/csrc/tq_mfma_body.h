@@ -68,6 +68,13 @@ __device__ __forceinline__ void split4(uint32_t a, uint32_t b, uint32_t c, uint3
     lo = perm(cd, ab, 0x05040100u) ^ 0x80808080u;
     hi = perm(cd, ab, 0x07060302u);
 }
+// the same for the fields at bits [8, 24) of the four values (no shift needed to reach them)
+__device__ __forceinline__ void split4_b8(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t &hi, uint32_t &lo)
+{
+    const uint32_t ab = perm(b, a, 0x06020501u), cd = perm(d, c, 0x06020501u);  // a1 b1 a2 b2
+    lo = perm(cd, ab, 0x05040100u) ^ 0x80808080u;
+    hi = perm(cd, ab, 0x07060302u);
+}
 // two Int16 pairs {b, a}, {d, c} -> the same
 __device__ __forceinline__ void split2x2(uint32_t ba, uint32_t dc, uint32_t &hi, uint32_t &lo)
 {
@@ -78,6 +85,18 @@ __device__ __forceinline__ uint32_t sat_pk_u8_i16(uint32_t pair)  // {sat8(hi), 
 {
     uint32_t r;
     asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(pair));
+    return r;
+}
+__device__ __forceinline__ int bfi(int mask, int a, int b)  // mask ? a : b, bit by bit: v_bfi_b32
+{
+    int r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int mad24(int a, int b, int c)  // a * b + c on the low 24 bits of a and b: v_mad_i32_i24
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
 __device__ __forceinline__ uint32_t sad_u32(uint32_t a, uint32_t b, uint32_t acc)  // |a - b| + acc: v_sad_u32
@@ -171,7 +190,7 @@ __device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, co
     const v4i f3 = *reinterpret_cast<const v4i *>(F.f3[lane]);
     v16i cin_i1, cin_i2;  // accumulator starts of the inverse passes: rounding + the low-byte bias
     if constexpr (MODE & TQ_INV) {
-        const int k1 = 64 + F.kappa[c];  // SHIFT_INV_1ST = 7; output index = the lane
+        const int k1 = 2 * (64 + F.kappa[c]);  // SHIFT_INV_1ST = 7; output index = the lane; twice: see inverse pass 1
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             cin_i1[r] = k1;
@@ -368,7 +387,8 @@ __device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, co
                 if constexpr (N == 4) t += rnd2;
                 cf[r] = field16<sh2>(t);  // truncating Int16 store of the coefficient
                 // xQuant
-                const int q = mul24(cf[r], (int)p.q_scale) + (cf[r] < 0 ? q_neg : q_pos);
+                const int sg = cf[r] >> 31;  // all ones for a negative coefficient
+                const int q = mad24(cf[r], (int)p.q_scale, bfi(sg, q_neg, q_pos));
                 const uint32_t lb = (uint32_t)q >> p.q_bits;   // level + q_bias
                 psum[r >> 2] = sad_u32(lb, q_bias, psum[r >> 2]);
                 level[r] = (int)(lb - q_bias);
@@ -444,27 +464,42 @@ __device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, co
         if constexpr (MODE & TQ_INV) {
             // ================= xDeQuant (src/pixel.cpp:649-650): clip16((level * scale + rnd) >> shift) =================
             uint32_t dh[4], dl[4];
+            // QP / 6 >= log2 N - 1: the scale has taken the shift in (quant_constants) and the stage is one multiply
+            if (p.dq_shift == 0) {  // wave-uniform
 #pragma unroll
-            for (int g4 = 0; g4 < 4; g4++) {
-                int v[4];
+                for (int g4 = 0; g4 < 4; g4++) {
+                    int v[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) v[k] = (mul24(level[4 * g4 + k], p.dq_scale) + p.dq_rnd) >> p.dq_shift;
-                // v_cvt_pk_i16_i32 saturates: the clip and the pack in one
-                const uint32_t p0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0], v[1]));
-                const uint32_t p1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2], v[3]));
-                split2x2(p0, p1, dh[g4], dl[g4]);
+                    for (int k = 0; k < 4; k++) v[k] = mul24(level[4 * g4 + k], p.dq_scale);
+                    // v_cvt_pk_i16_i32 saturates: the clip and the pack in one
+                    const uint32_t p0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0], v[1]));
+                    const uint32_t p1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2], v[3]));
+                    split2x2(p0, p1, dh[g4], dl[g4]);
+                }
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    int v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) v[k] = (mul24(level[4 * g4 + k], p.dq_scale) + p.dq_rnd) >> p.dq_shift;
+                    const uint32_t p0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[0], v[1]));
+                    const uint32_t p1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(v[2], v[3]));
+                    split2x2(p0, p1, dh[g4], dl[g4]);
+                }
             }
             // ================= inverse pass 1 (columns): coefficients^T x T =================
+            // The low-byte product is taken TWICE (the matrix pipe has room, the vector ALU has none): twice the sum puts
+            // the Int16 that (sum + 64) >> 7 leaves at bits [8, 24), on a byte boundary, and saves the shift per value.
             v16i ah = mfma(as_v4i(dh), f3, splat16(0));
-            v16i al = mfma(as_v4i(dl), f3, cin_i1);
+            v16i al = mfma(as_v4i(dl), f3, mfma(as_v4i(dl), f3, cin_i1));
             // (sum + 64) >> 7, store-then-clip = wrap (src/pixel.cpp:334-342); lane = picture row now
             uint32_t uh[4], ul[4];
 #pragma unroll
             for (int g4 = 0; g4 < 4; g4++) {
                 uint32_t t[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) t[k] = (((uint32_t)ah[4 * g4 + k] << 8) + (uint32_t)al[4 * g4 + k]) >> 7;
-                split4(t[0], t[1], t[2], t[3], uh[g4], ul[g4]);
+                for (int k = 0; k < 4; k++) t[k] = ((uint32_t)ah[4 * g4 + k] << 9) + (uint32_t)al[4 * g4 + k];
+                split4_b8(t[0], t[1], t[2], t[3], uh[g4], ul[g4]);
             }
             // ================= inverse pass 2 (rows): T^T x intermediate =================
             ah = mfma(f3, as_v4i(uh), splat16(0));
