@@ -267,7 +267,9 @@ __device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, co
         return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(mv_rs, (int)(idx * 8u), 0, 0);  // entry 0 exists
     };
     // the lane's 16 bytes of its picture row (lane = row c of the tile, bytes 16 h .. 16 h + 15)
-    auto load_rows = [&](const TilePos &pos, bool active, uint32_t mv, uint32_t (&sw)[4], uint32_t (&pw)[4]) {
+    // (with vectors: pw = the five aligned dwords the compensated row lies in, psh = its byte offset in the first;
+    //  pred_align shifts the row out where it is USED -- here it would make the wave wait for the loads)
+    auto load_rows = [&](const TilePos &pos, bool active, uint32_t mv, uint32_t (&sw)[4], uint32_t (&pw)[5], uint32_t &psh) {
         const Geo g = geo(pos);
         const int f = active ? pos.f : 0;
         const __amdgpu_buffer_rsrc_t pred_rs = pred_rsrc(f);
@@ -290,9 +292,24 @@ __device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, co
         // hold never reaches a valid output (rows and columns past the picture belong to transform units that
         // lie wholly outside it, and the matrices are block-diagonal per unit).  No select on the loaded VALUES:
         // it would make the wave wait for them here, and these loads are a tile ahead of their use.
-        const v4i a = __builtin_amdgcn_raw_buffer_load_b128(pred_rs, (int)(row_ok ? pofs : kPredBias), 0, 0);
+        psh = 0;
+        pw[4] = 0;
+        if constexpr (have_mv) {
+            // a compensated row starts at any byte: the four aligned dwords it begins in and, unless it is aligned itself,
+            // the one behind them (never a byte past the dword that holds the row's last sample).  An unaligned 16-byte
+            // load costs the memory pipeline more than the two aligned ones.
+            const uint32_t po = row_ok ? pofs : kPredBias;
+            const uint32_t pa = po & ~3u;
+            psh = po & 3u;
+            const v4i a = __builtin_amdgcn_raw_buffer_load_b128(pred_rs, (int)pa, 0, 0);
+            pw[4] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(pred_rs, (int)(pa + (psh ? 16u : 12u)), 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; i++) pw[i] = (uint32_t)a[i];
+            for (int i = 0; i < 4; i++) pw[i] = (uint32_t)a[i];
+        } else {
+            const v4i a = __builtin_amdgcn_raw_buffer_load_b128(pred_rs, (int)(row_ok ? pofs : kPredBias), 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) pw[i] = (uint32_t)a[i];
+        }
         if constexpr (MODE & TQ_FWD) {
             const v4i b = __builtin_amdgcn_raw_buffer_load_b128(src_rs, (int)(row_ok ? soff : kOob), 0, 0);
 #pragma unroll
@@ -326,18 +343,21 @@ __device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, co
     advance(pos1);
     TilePos pos2 = pos1;
     advance(pos2);
-    uint32_t srcw[4], predw[4], src_nx[4], pred_nx[4];
-    load_rows(pos0, true, load_mv(pos0, true), srcw, predw);
+    uint32_t srcw[4], predr[5], src_nx[4], pred_nx[5], psh = 0, psh_nx = 0;  // predr: the prediction row as loaded
+    load_rows(pos0, true, load_mv(pos0, true), srcw, predr, psh);
     uint32_t mv1 = load_mv(pos1, u_beg + 1 < u_end);
     // everything loaded so far is waited for before the loop, so that inside it only its own prefetches are pending
-    asm volatile("" ::"v"(srcw[0]), "v"(srcw[1]), "v"(srcw[2]), "v"(srcw[3]), "v"(predw[0]), "v"(predw[1]), "v"(predw[2]),
-                 "v"(predw[3]), "v"(mv1), "v"(f1), "v"(f2), "v"(f3));
+    asm volatile("" ::"v"(srcw[0]), "v"(srcw[1]), "v"(srcw[2]), "v"(srcw[3]), "v"(predr[0]), "v"(predr[1]), "v"(predr[2]),
+                 "v"(predr[3]), "v"(predr[4]), "v"(mv1), "v"(f1), "v"(f2), "v"(f3));
 
 #pragma unroll 1
     for (int u = u_beg; u < u_end; u++) {
         // the next unit's rows and the vectors of the one after it are on their way while this one is transformed
-        load_rows(pos1, u + 1 < u_end, mv1, src_nx, pred_nx);
+        load_rows(pos1, u + 1 < u_end, mv1, src_nx, pred_nx, psh_nx);
         const uint32_t mv2 = load_mv(pos2, u + 2 < u_end);
+        uint32_t predw[4];  // this tile's prediction row: arrived an iteration ago
+#pragma unroll
+        for (int i = 0; i < 4; i++) predw[i] = have_mv ? __builtin_amdgcn_alignbyte(predr[i + 1], predr[i], psh) : predr[i];
 
         const Geo g = geo(pos0);
         if (g.tile_ok) {  // wave-uniform (the last group of a tile row may hold fewer than four tiles)
@@ -398,7 +418,7 @@ __device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, co
             // per tile for the stores.  By now the loads have had the whole forward half of the tile to arrive.
             // (level[15] among the operands keeps the scheduler from moving the wait up ahead of the quantiser.)
             asm volatile("" ::"v"(src_nx[0]), "v"(src_nx[1]), "v"(src_nx[2]), "v"(src_nx[3]), "v"(pred_nx[0]), "v"(pred_nx[1]),
-                         "v"(pred_nx[2]), "v"(pred_nx[3]), "v"(mv2), "v"(level[15]), "v"(level[0]));
+                         "v"(pred_nx[2]), "v"(pred_nx[3]), "v"(pred_nx[4]), "v"(mv2), "v"(level[15]), "v"(level[0]));
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 __builtin_amdgcn_raw_buffer_store_b16((short)level[r], lvl_rs, lv_off, rho(r, 0) * row_bytes, 0);
@@ -535,13 +555,13 @@ __device__ __forceinline__ void tq_mfma_body(const TqParams &p, const int bx, co
         }
         } else {  // the same wait on the path that skips the tile
             asm volatile("" ::"v"(src_nx[0]), "v"(src_nx[1]), "v"(src_nx[2]), "v"(src_nx[3]), "v"(pred_nx[0]), "v"(pred_nx[1]),
-                         "v"(pred_nx[2]), "v"(pred_nx[3]), "v"(mv2));
+                         "v"(pred_nx[2]), "v"(pred_nx[3]), "v"(pred_nx[4]), "v"(mv2));
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            srcw[i] = src_nx[i];
-            predw[i] = pred_nx[i];
-        }
+        for (int i = 0; i < 4; i++) srcw[i] = src_nx[i];
+#pragma unroll
+        for (int i = 0; i < 5; i++) predr[i] = pred_nx[i];
+        psh = psh_nx;
         mv1 = mv2;
         pos0 = pos1;
         pos1 = pos2;
