@@ -50,7 +50,7 @@ WORKLOADS = {
     # name: (nominal W, nominal H, CTU, R, nrefs, frames per step, TU, QP)
     "1080p": (1920, 1080, 64, 64, 1, 16, 32, 32),     # BASELINE.json configs[1]
     "4k": (3840, 2160, 64, 128, 1, 4, 32, 32),        # configs[3]: one GOP segment of 4 per step
-    "8k4ref": (7680, 4320, 64, 64, 4, 2, 32, 32),     # configs[4]
+    "8k4ref": (7680, 4320, 64, 64, 4, 8, 32, 32),     # configs[4]: the whole GOP of 8 frames resident per GPU
     "tq1080p": (1920, 1080, 64, 0, 1, 16, 32, 32),    # configs[2]: transform/quant only (see --tu), no search
     "gop1080p": (1920, 1080, 64, 64, 1, 16, 32, 32),  # closed-loop P pictures, 16 GOP segments, 4:2:0
     "intra1080p": (1920, 1080, 32, 0, 0, 16, 32, 32),  # the reference's own picture type, CU 32, 16 frames per step
@@ -222,14 +222,19 @@ def kernel_split(pipe, reps):
             if k != "_"}
 
 
-def worst_case(w, h, ctu, rng, nrefs, nominal_px):
-    """Content on which elimination cannot eliminate: white noise (bounds useless) and a flat picture (every
-    candidate ties).  Search stage only, 4 frames per launch, both entry points; identical output required."""
+def other_content(w, h, ctu, rng, nrefs, nominal_px, which):
+    """The search stage on other content than the headline's, 4 frames per launch, both entry points; identical output
+    required.  which = "worst": white noise (bounds useless) and a flat picture (every candidate ties);
+    "mid": 1/f-like texture in which every CTU moves with its own vector (synth.make_textured_sequence)."""
     out = {}
     g = np.random.default_rng(0)
     nf = 4
-    for name, frames in (("noise", g.integers(0, 256, (nf + nrefs, h, w), dtype=np.uint8)),
-                         ("flat", np.full((nf + nrefs, h, w), 77, np.uint8))):
+    if which == "worst":
+        cases = (("noise", g.integers(0, 256, (nf + nrefs, h, w), dtype=np.uint8)),
+                 ("flat", np.full((nf + nrefs, h, w), 77, np.uint8)))
+    else:
+        cases = (("textured", synth.make_textured_sequence(w, h, nf + nrefs, search_range=rng, ctu=ctu)),)
+    for name, frames in cases:
         fr = torch.from_numpy(frames).cuda()
         res = {}
         keep = None
@@ -253,9 +258,14 @@ def worst_case(w, h, ctu, rng, nrefs, nominal_px):
                 res["identical_output"] = bool(torch.equal(keep, mv))
             del pipe
         out[name] = res
-    out["note"] = ("search stage only, 4 frames per launch; sea = x265amd_me_fullsearch_sea (the measured path), brute = "
-                   "x265amd_me_fullsearch (every candidate's SAD): nothing can be eliminated on this content, so the "
-                   "headline's rate does not apply to it")
+    if which == "worst":
+        out["note"] = ("search stage only, 4 frames per launch; sea = x265amd_me_fullsearch_sea (the measured path), brute = "
+                       "x265amd_me_fullsearch (every candidate's SAD).  Noise: the bounds eliminate nothing, the blocks go to the "
+                       "every-candidate kernel behind the bounds pass (me_list_qsad); flat: every candidate ties, the search ends "
+                       "after the first batch (ties go to the lower raster index).  The headline's rate does not apply here")
+    else:
+        out["note"] = ("search stage only, 4 frames per launch: 1/f-like texture, every CTU with its own vector in [-R/2, R/2]^2 "
+                       "(synth.make_textured_sequence) -- between the headline's smooth content and white noise")
     return out
 
 
@@ -641,15 +651,19 @@ def search_and_tq(args, grp, nw, nh, ctu, rng, nrefs, fps, tu, qp):
                        "dist_backend": grp.backend if world > 1 else None},
             "roofline": {"kernel": "search stage = box16_pairs + sea_bounds_kernel + sea_exact_kernel (dominant)"
                                    if pipe.method == "sea" else "me_fullsearch_qsad",
-                         "bound": "hbm", "binding_resource": "valu (v_qsad_pk_u16_u8 issue; see valu)",
+                         "bound": "valu",
+                         "bound_note": "integer VALU (v_qsad_pk_u16_u8 issue) binds this stage, see `valu`; achieved / peak / frac "
+                                       "below are the HBM figures BASELINE.json's metric asks for (algorithmic bytes / stage time)",
                          "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic(args.workload, "me_bytes_per_launch"),
-                         "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                           "command, tools/run_pmc.sh)",
+                         "traffic_source": "committed PMC pass, not measured in this run: profiles/pmc_traffic.json (rocprofv3 --pmc "
+                                           "FETCH_SIZE / WRITE_SIZE passes of this command, tools/run_pmc.sh)",
                          "algorithmic_bytes_per_launch": me_bytes,
                          "avg_launch_ms": round(me_ms, 4), "kernels_ms": kernels_ms,
-                         "note": "avg_launch_ms = the whole search stage per step (sum of its kernels; compare the "
+                         "note": "avg_launch_ms comes from the event-instrumented steps (every fourth), which run ~2 % slower than "
+                                 "the plain ones that ms_per_step averages over: every frac in this line is understated by "
+                                 "about that much.  avg_launch_ms = the whole search stage per step (sum of its kernels; compare the "
                                  "sum of their averages in profiles/*kernel_stats.csv).  Exhaustive SAD search is "
                                  "integer-VALU bound, not HBM bound (SURVEY.md 8d): `valu` is its roofline.  traffic "
                                  "counts fabric requests, Infinity-Cache hits included (window overlap between "
@@ -667,7 +681,8 @@ def search_and_tq(args, grp, nw, nh, ctu, rng, nrefs, fps, tu, qp):
             out["cpu_baseline"] = cpu_baseline(frames_np, ctu, rng, nrefs, tu, qp, gmv, pipe.level[0].cpu().numpy(),
                                                pipe.rec[0].cpu().numpy(), nw * nh)
             if args.workload == "1080p":
-                out["worst_case"] = worst_case(w, h, ctu, rng, nrefs, nw * nh)
+                out["mid_case"] = other_content(w, h, ctu, rng, nrefs, nw * nh, "mid")
+                out["worst_case"] = other_content(w, h, ctu, rng, nrefs, nw * nh, "worst")
         print(json.dumps(out), flush=True)
     grp.close()
 

@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <exception>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -329,21 +330,19 @@ class IntraEncoder {
         poc_ += n;
         const int nt = threads < 1 ? 1 : threads > n ? n : threads;
         std::vector<std::thread> pool;
-        std::vector<std::string> errors((size_t)nt);
-        std::vector<int> status((size_t)nt, X265AMD_OK);
+        std::vector<std::exception_ptr> failed((size_t)nt);
         for (int t = 0; t < nt; t++)
             pool.emplace_back([&, t] {
                 try {
                     for (int k = t; k < n; k += nt)
                         write_at(first + k, level + (size_t)k * fsz_, mode_y + (size_t)k * ncu_, mode_c + (size_t)k * ncu_, out[(size_t)k]);
-                } catch (const Error &e) {
-                    status[(size_t)t] = e.status;
-                    errors[(size_t)t] = e.what();
+                } catch (...) {  // a library status, or the host running out of memory: nothing may leave a thread
+                    failed[(size_t)t] = std::current_exception();
                 }
             });
         for (auto &th : pool) th.join();
         for (int t = 0; t < nt; t++)
-            if (status[(size_t)t] != X265AMD_OK) throw Error(status[(size_t)t], "IntraEncoder::write_pictures");
+            if (failed[(size_t)t]) std::rethrow_exception(failed[(size_t)t]);  // the first worker's own exception, message and all
     }
 
   private:

@@ -194,7 +194,7 @@ int x265amd_me_fullsearch_pu(const uint8_t *d_cur, const uint8_t *d_ref, int wid
  * the w_s x h_s blocks tiling the picture: for each the first strict SAD minimum in raster order over the
  * displacements that keep THAT block inside the picture (src/encode.cpp:725-727, 762-765), i.e. what
  * x265amd_me_fullsearch returns for the square shapes.  Entries may be NULL (not all).  width, height multiples
- * of 64; range <= 181; the unclipped (64 + 2*range)^2 window must fit in LDS, else X265AMD_ERR_LDS. */
+ * of 64; range <= 180; the unclipped (64 + 2*range)^2 window must fit in LDS, else X265AMD_ERR_LDS. */
 enum x265amd_pu_shape {
     X265AMD_PU_64x64 = 0,
     X265AMD_PU_64x32,
@@ -287,7 +287,9 @@ int x265amd_intra_encode_frames(const x265amd_intra_frame *frame, int nframes, i
  *   mode_c: the real chroma mode, as x265amd_intra_frame.d_mode_c holds it; X265AMD_ERR_ARG if it is not one of
  *     the reference's candidates for the CU's luma mode (src/encode.cpp:781-793)
  *   out / cap: receives the bytes; X265AMD_ERR_BUFFER if cap is too small (*bytes then holds the size needed);
- *     x265amd_intra_stream_bound(width, height) is always enough. */
+ *     x265amd_intra_stream_bound(width, height) (7 bytes per sample) is enough for any levels the library's own
+ *     quantiser produces and for planes of full-range Int16 levels at random (tests/test_intra_stream.py pins
+ *     both); a plane built to be hostile that overruns it is refused with X265AMD_ERR_BUFFER, never written past. */
 typedef struct x265amd_intra_syntax {
     int32_t width, height, cu, qp, poc;
     int32_t stride_y, stride_c;                    /* of the level planes, in elements */
@@ -319,7 +321,8 @@ typedef struct x265amd_tq_desc {
      * vector of the mv_ctu x mv_ctu block containing (x, y) -- integer-pel motion
      * compensation fused into the load (see mv_shift below).  The vectors must keep every compensated
      * block inside the prediction plane, as the library's own searches guarantee ("legal" candidates,
-     * SURVEY App. A.7): the kernels do not clamp, a vector from elsewhere that points outside reads outside. */
+     * SURVEY App. A.7): the kernels do not clamp, a vector from elsewhere that points outside reads outside --
+     * unless `flags` asks for the check (X265AMD_TQ_CHECK_MV below). */
     const uint8_t *d_pred;
     int32_t pred_stride;
     int64_t pred_frame_stride;
@@ -349,8 +352,14 @@ typedef struct x265amd_tq_desc {
      * 0 for the plane the search ran on; 1 for the 4:2:0 chroma planes of the same picture (luma
      * vectors, mv_ctu = half the luma CTU).  0..3. */
     int32_t mv_shift;
-    int32_t reserved; /* 0 */
+    /* X265AMD_TQ_* bits, 0 by default.  X265AMD_TQ_CHECK_MV (with d_mv): before anything else a kernel checks that
+     * every vector keeps its mv_ctu x mv_ctu block inside the width x height plane at d_pred; the call waits for it
+     * (one stream synchronisation, calls with the flag are serialised per process) and returns X265AMD_ERR_ARG,
+     * with nothing transformed, if one does not.  For vectors that did not come from this library's searches.
+     * Other bits: X265AMD_ERR_ARG. */
+    int32_t flags;
 } x265amd_tq_desc;
+#define X265AMD_TQ_CHECK_MV 1
 
 /* xSubDct + xQuant for every TU of the plane(s)
  * (inc/x265.h:295,297; src/pixel.cpp:668-722,591-633; call site src/encode.cpp:868-873). */

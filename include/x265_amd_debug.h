@@ -3,9 +3,11 @@
  * (include/x265_amd.h): tools/, bench.py and the tests use them to time kernels, count the work of the
  * elimination search, try kernel shapes and reach the cross-check formulation of the search.
  *
- * All of them are process-global and unsynchronised: one device, one thread.  A product build may drop
- * them; nothing in include/x265_amd.h depends on them.  The reference has no counterpart (its only
- * instrumentation is the CHECK_TV harness, src/testvec.cpp).
+ * The switches are PER DEVICE, like all of the library's state: a setter changes the device that is current on the
+ * calling thread (after x265amd_init for it; before that it does nothing), and only calls made on that device see
+ * the change.  They are not synchronised with launches in flight on other host threads of the same device: set them
+ * while that device is quiet.  Nothing in include/x265_amd.h depends on them.  The reference has no counterpart
+ * (its only instrumentation is the CHECK_TV harness, src/testvec.cpp).
  */
 #ifndef X265_AMD_DEBUG_H
 #define X265_AMD_DEBUG_H
@@ -19,11 +21,12 @@ extern "C" {
 /* d_stats != NULL: the successive-elimination kernels run their statistics variants and write 16 u32 per
  * (plane, CTU): [0] / [1] groups of four candidates evaluated in the first batch / the second pass, [2..6]
  * cycle stamps of the exact kernel, [8] the work estimate, [10..13] cycle stamps of the bounds kernel.
- * NULL switches back.  Applies to every later x265amd_me_fullsearch_sea[_static] call of the process. */
+ * [14] / [15] lower halves finished of the second pass / the first batch.  NULL switches back.  Applies to every
+ * later x265amd_me_fullsearch_sea[_static] call on this device. */
 void x265amd_debug_set_me_stats(uint32_t *d_stats);
 
 /* HIP events around the three kernels of x265amd_me_fullsearch_sea on the call's own stream; _last_ms
- * waits for the last timed call and returns {box16_pairs, 0, sea_bounds_kernel, sea_exact_kernel} in ms. */
+ * waits for the last timed call and returns {box16_pairs, 0, sea_bounds_kernel, sea_exact_kernel + me_list_qsad} in ms. */
 int x265amd_debug_me_timing(int enable);
 int x265amd_debug_me_last_ms(float *out4);
 
@@ -48,7 +51,7 @@ void x265amd_debug_intra_threads(int threads);
 /* Where and when the waves of the matrix-core TQ kernel ran: with a non-null device buffer of nwaves x 4
  * 64-bit words (nwaves >= 4 x the workgroups of the launch, else nothing is recorded; zeroed by the caller) every wave of the following
  * launches of that kernel leaves {start, end (100 MHz wall clock), shader clocks spent,
- * XCC_ID << 32 | HW_ID} at record 4 * workgroup + wave.  Null switches it off.  Process-wide like the hooks
+ * XCC_ID << 32 | HW_ID} at record 4 * workgroup + wave.  Null switches it off.  Per device like the hooks
  * above; tools/tq_trace.py prints the launch ramp, the spread of the durations and the clock from it. */
 void x265amd_debug_tq_trace(unsigned long long *d_records, int nwaves);
 

@@ -71,11 +71,12 @@ def _batch_properties(gpu, oracle, W, H, R, nframes, nrefs, oracle_step, seed=12
 
 
 def test_me_8k_four_references_full_size(gpu, oracle):
-    """BASELINE.json configs[4]: 7680x4320 (padded to 4352), 4 reference frames, R 64, two frames per launch:
-    8160 CTUs x 8 planes, 33 MB planes, 2.2 GB of workspace -- the sizes at which plane / CTU / workspace
-    indexing could overflow.  Oracle on every 499th CTU of every (frame, reference) plane."""
-    n = _batch_properties(gpu, oracle, 7680, 4352, 64, 2, 4, 499)
-    assert n >= 8 * 16
+    """BASELINE.json configs[4] as written (the whole GOP resident): 7680x4320 (padded to 4352), 4
+    reference frames, R 64, EIGHT frames per launch: 8160 CTUs x 32 planes, 33 MB planes, 9 GB of workspace -- the
+    sizes at which plane / CTU / workspace indexing could overflow.  Oracle on every 499th CTU of every (frame,
+    reference) plane."""
+    n = _batch_properties(gpu, oracle, 7680, 4352, 64, 8, 4, 499)
+    assert n >= 32 * 16
 
 
 def test_me_4k_gop_segment_batch(gpu, oracle):
@@ -109,3 +110,28 @@ def test_tq_1080p_chroma_plane_mv_shift(gpu, oracle):
         np.testing.assert_array_equal(host(level)[0], ol)
         np.testing.assert_array_equal(host(sums)[0].astype(np.uint32), os_)
         assert hashlib.md5(host(rec)[0].tobytes()).hexdigest() == hashlib.md5(orec.tobytes()).hexdigest()
+
+
+def test_bench_two_ranks_as_a_fresh_child(gpu):
+    """`python bench.py --gpus 2` started by hand on this box: the script launches its own two ranks before anything
+    touches the GPU (here they share the one device and meet over gloo), each searches and transforms its own shard of
+    ONE sequence, rank 0 prints the line.  Checks the line's shape, that both shards report a result digest and that
+    each rank's sample agreed with the CPU checker."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--lean"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["metric"] == "ME+TQ Mpixels/s" and line["value"] > 0
+    shards = line["shards"]
+    assert [s["rank"] for s in shards] == [0, 1]
+    assert shards[1]["first_frame"] == shards[0]["first_frame"] + shards[0]["frames"]      # consecutive runs of one sequence
+    assert all(len(s["mv_md5"]) == 32 and len(s["level_rec_md5"]) == 32 for s in shards)
+    assert shards[0]["mv_md5"] != shards[1]["mv_md5"]                                        # different frames, different vectors
+    assert all(s["sample_parity_vs_cpu"] for s in shards)

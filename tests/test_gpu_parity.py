@@ -442,6 +442,41 @@ def test_tq_mv_shift_chroma_vs_oracle(gpu, oracle):
     np.testing.assert_array_equal(host(rec)[0], orec)
 
 
+def test_tq_check_mv_rejects_vectors_that_leave_the_plane(gpu, oracle):
+    """X265AMD_TQ_CHECK_MV (x265amd_tq_desc.flags): a vector that takes its block outside the prediction plane is
+    refused with X265AMD_ERR_ARG before anything is transformed (the outputs keep their contents); legal vectors go
+    through and give the oracle's planes; unknown flag bits are refused."""
+    rng = np.random.default_rng(81)
+    H, W = 128, 192
+    src = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+    ref = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+    mv = np.zeros((2, 6), dtype=gpu.MV_DTYPE)
+    for f in range(2):
+        for i in range(6):
+            bx, by = (i % 3) * 64, (i // 3) * 64
+            mv["mvx"][f, i] = rng.integers(-bx, W - 64 - bx + 1)
+            mv["mvy"][f, i] = rng.integers(-by, H - 64 - by + 1)
+    dmv = torch.from_numpy(mv.view(np.int32).reshape(2, 6, 2).copy()).cuda()
+    level, sums, rec = gpu.tq_roundtrip(dev(src), dev(ref), 32, 30, 1, mv=dmv, mv_ctu=64, check_mv=True)
+    for f in range(2):
+        ol, os_ = oracle.tq_forward(src[f], ref[f], 32, 30, 1, mv=mv[f], mv_ctu=64)
+        np.testing.assert_array_equal(host(level)[f], ol)
+        np.testing.assert_array_equal(host(rec)[f], oracle.tq_inverse(ol, ref[f], 32, 30, 1, mv=mv[f], mv_ctu=64))
+    for (f, i, field, val) in ((1, 5, "mvx", 1), (0, 0, "mvy", -1), (1, 2, "mvx", 32767), (0, 3, "mvy", 65)):
+        bad = mv.copy()
+        bad[field][f, i] = val if abs(val) > 1 else (W - 64 - (i % 3) * 64 + 1 if field == "mvx" else -((i // 3) * 64) - 1)
+        dbad = torch.from_numpy(bad.view(np.int32).reshape(2, 6, 2).copy()).cuda()
+        out = (torch.full_like(level, 77), torch.full_like(sums, 7), torch.full_like(rec, 9))
+        with pytest.raises(gpu.X265AmdError) as e:
+            gpu.tq_roundtrip(dev(src), dev(ref), 32, 30, 1, mv=dbad, mv_ctu=64, check_mv=True, out=out)
+        assert e.value.status == -1                       # X265AMD_ERR_ARG
+        torch.cuda.synchronize()
+        assert (out[0] == 77).all() and (out[2] == 9).all()   # nothing was launched
+    d = gpu.api._tq_desc(32, 30, 1, src=dev(src), pred=dev(ref), mv=dmv, mv_ctu=64, level=level, abs_sum=sums, rec=rec)
+    d.flags = 2
+    assert gpu.api._lib().x265amd_tq_roundtrip(gpu.api.C.byref(d), None) == -1
+
+
 @pytest.mark.parametrize("ctu,rng_,w,h", [(64, 40, 320, 192), (32, 33, 224, 160), (16, 21, 144, 112)])
 def test_me_production_kernel_equals_basic_formulation(gpu, ctu, rng_, w, h):
     """The qsad kernel (all three block sizes) against the independent one-candidate-per-lane

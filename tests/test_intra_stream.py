@@ -93,3 +93,23 @@ def test_writer_rejects_what_the_reference_cannot_code():
     n = C.c_size_t(0)
     assert lib.x265amd_intra_write_picture(C.byref(d), buf.ctypes.data, 16, C.byref(n)) == -7
     assert n.value == len(ok) and (buf[16:] == 0xAA).all() and buf[:16].tobytes() == ok[:16].tobytes()
+
+
+@pytest.mark.parametrize("cu", [16, 32])
+def test_stream_bound_holds_for_full_range_levels(cu):
+    """x265amd_intra_stream_bound (7 bytes per sample): pictures whose every level is +-32767 or -32768 -- the most bins a
+    level can cost (Golomb-Rice prefix, Exp-Golomb escape, sign, the context-coded flags) -- and full-range levels at
+    random stay under it, at both CU sizes."""
+    w, h = 64, 64
+    rng = np.random.default_rng(cu)
+    ncu = (w // cu) * (h // cu)
+    my = rng.integers(0, 35, ncu).astype(np.uint8)
+    bound = api._lib().x265amd_intra_stream_bound(w, h)
+    assert bound == 256 + 7 * w * h * 3 // 2
+    for name, lv in (("+32767", np.full(w * h * 3 // 2, 32767, np.int16)),
+                     ("-32768", np.full(w * h * 3 // 2, -32768, np.int16)),
+                     ("alternating", np.where(np.arange(w * h * 3 // 2) & 1, 32767, -32768).astype(np.int16)),
+                     ("random", rng.integers(-32768, 32768, w * h * 3 // 2).astype(np.int16))):
+        bits = x265_amd.intra_write_picture(*_planes(lv, w, h), my, my, cu, 30, 0)
+        assert 0 < len(bits) <= bound, (name, len(bits), bound)
+        assert len(bits) > w * h * 3 // 2 * 3, name      # such a picture does cost several bytes per sample

@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("X265AMD_LIB_PATH") or os.path.join(_HERE, "lib", "lib
 
 MODE_INVALID = 255            # inc/x265.h:70
 SLICE_I, SLICE_P, SLICE_B = 0, 1, 2   # inc/x265.h:39-43
+TQ_CHECK_MV = 1                        # x265amd_tq_desc.flags: verify the vectors before transforming
 MAX_SAD = 1 << 30             # inc/config.h:52
 
 MV_DTYPE = np.dtype([("mvx", "<i2"), ("mvy", "<i2"), ("sad", "<u4")])
@@ -40,7 +41,7 @@ class TqDesc(C.Structure):
         ("d_coef", C.c_void_p),
         ("d_abs_sum", C.c_void_p), ("abs_sum_frame_stride", C.c_int64),
         ("d_rec", C.c_void_p), ("rec_stride", C.c_int32), ("rec_frame_stride", C.c_int64),
-        ("mv_shift", C.c_int32), ("reserved", C.c_int32),
+        ("mv_shift", C.c_int32), ("flags", C.c_int32),
     ]
 
 
@@ -540,8 +541,9 @@ def mv_to_numpy(mv):
 # xSubDct + xQuant / xDeQuant + xIDctAdd (inc/x265.h:295-298)
 # --------------------------------------------------------------------------
 def _tq_desc(tu, qp, slice_type, src=None, pred=None, mv=None, mv_ctu=64, modes=None, level=None, coef=None,
-             abs_sum=None, rec=None, pred_origin=(0, 0), mv_shift=0):
+             abs_sum=None, rec=None, pred_origin=(0, 0), mv_shift=0, check_mv=False):
     d = TqDesc()
+    d.flags = TQ_CHECK_MV if check_mv else 0
     geom = None
     if src is not None:
         d.d_src, f, h, w, d.src_stride, d.src_frame_stride = _planes(src, torch.uint8, "src")
@@ -601,13 +603,13 @@ def _alloc_like(src, dtype, tu=None):
 
 
 def tq_forward(src, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, want_coef=False,
-               pred_origin=(0, 0), mv_shift=0):
+               pred_origin=(0, 0), mv_shift=0, check_mv=False):
     """xSubDct + xQuant over whole planes.  Returns (level, abs_sum[, coef])."""
     level = _alloc_like(src, torch.int16)
     sums = _alloc_like(src, torch.int32, tu if tu in (4, 8, 16, 32) else 4)
     coef = _alloc_like(src, torch.int16) if want_coef else None
     d = _tq_desc(tu, qp, slice_type, src=src, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level,
-                 coef=coef, abs_sum=sums, pred_origin=pred_origin, mv_shift=mv_shift)
+                 coef=coef, abs_sum=sums, pred_origin=pred_origin, mv_shift=mv_shift, check_mv=check_mv)
     _check(_lib().x265amd_tq_forward(C.byref(d), _stream()), "x265amd_tq_forward")
     return (level, sums, coef) if want_coef else (level, sums)
 
@@ -631,7 +633,7 @@ def idct_add(coef, pred, tu, modes=None, pred_origin=(0, 0)):
 
 
 def tq_roundtrip(src, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, modes=None, pred_origin=(0, 0),
-                 out=None, mv_shift=0):
+                 out=None, mv_shift=0, check_mv=False):
     """Fused forward + inverse (src/encode.cpp:863-925).  Returns (level, abs_sum, rec).
     `out` = (level, abs_sum, rec) preallocated tensors to reuse (no allocation in the call)."""
     if out is None:
@@ -641,7 +643,7 @@ def tq_roundtrip(src, pred, tu, qp, slice_type=SLICE_I, mv=None, mv_ctu=64, mode
     else:
         level, sums, rec = out
     d = _tq_desc(tu, qp, slice_type, src=src, pred=pred, mv=mv, mv_ctu=mv_ctu, modes=modes, level=level,
-                 abs_sum=sums, rec=rec, pred_origin=pred_origin, mv_shift=mv_shift)
+                 abs_sum=sums, rec=rec, pred_origin=pred_origin, mv_shift=mv_shift, check_mv=check_mv)
     _check(_lib().x265amd_tq_roundtrip(C.byref(d), _stream()), "x265amd_tq_roundtrip")
     return level, sums, rec
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "../../include/x265_amd.h"
@@ -32,16 +33,37 @@ struct OccEntry {  // occupancy of one kernel variant at one dynamic-LDS size
     int per_cu;
 };
 
+// Instrumentation switches (include/x265_amd_debug.h), per device like everything else: a setter changes the device
+// that is current on the calling thread, and only calls on that device see it.
+struct DebugState {
+    uint32_t *me_stats = nullptr;         // x265amd_debug_set_me_stats
+    bool me_timing = false;               // x265amd_debug_me_timing
+    hipEvent_t me_ev[5] = {};
+    int sea_lds_pad = 0, sea_waves = 0;   // x265amd_debug_sea_shape
+    int tq_path = 0;                      // x265amd_debug_tq_path
+    unsigned long long *tq_trace = nullptr;  // x265amd_debug_tq_trace
+    int tq_trace_waves = 0;
+    int tq_units_per_wg = 0;              // x265amd_debug_tq_units_per_wg
+    int intra_fused = 1;                  // x265amd_debug_intra_fused
+    int intra_threads = 0;                // x265amd_debug_intra_threads
+};
+
 struct DeviceState {
-    bool init = false;
+    std::atomic<bool> init{false};  // stored last by x265amd_init (release), read by device_state() (acquire)
     int lds_limit = 64 * 1024;  // hipDeviceAttributeMaxSharedMemoryPerBlock (160 KiB on gfx950)
     int cu_count = 256;
     void *sea_scratch = nullptr;     // device address of me_sea.hip's static scratch array ON THIS DEVICE
     size_t sea_scratch_bytes = 0;
     void *dropin_stage = nullptr;    // dropin.hip's staging block on this device
+    uint32_t *host_word = nullptr;   // one page-locked, device-visible word (x265amd_init): verdicts of checking kernels
+    uint32_t *host_word_dev = nullptr;  // .. as the device addresses it
     OccEntry occ[kOccSlots] = {};
     int nocc = 0;
+    DebugState dbg;
 };
+
+// the current device's instrumentation switches, or a block of defaults before x265amd_init
+DebugState &debug_state();
 
 // state of the device that is current on this thread; nullptr until x265amd_init() has run for it
 DeviceState *device_state();

@@ -598,9 +598,7 @@ static int intra_frame_check(const x265amd_intra_frame *f)
 }
 
 // x265amd_debug_intra_fused (include/x265_amd_debug.h): 0 keeps the transform stage a launch of its own (A/B runs)
-static int g_intra_fused = 1;
 // x265amd_debug_intra_threads: threads per workgroup of the prediction kernel, 256, 512 or 1024 (0 = by the step's size)
-static int g_intra_threads = 0;
 
 struct IntraBatch {
     int nframes;
@@ -631,7 +629,8 @@ static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st
     // more CUs in the step than the chip has compute units: the 8-wave shape, two workgroups to a compute unit; more
     // than twice as many: 4 waves, four to a compute unit
     const int64_t nwg = (int64_t)(hi - lo + 1) * b.nframes;
-    const int threads = g_intra_threads ? g_intra_threads : nwg > 2 * cu_count() ? 256 : nwg > cu_count() ? 512 : 1024;
+    const int forced_threads = debug_state().intra_threads;
+    const int threads = forced_threads ? forced_threads : nwg > 2 * cu_count() ? 256 : nwg > cu_count() ? 512 : 1024;
     const dim3 grid((unsigned)(hi - lo + 1), (unsigned)b.nframes), block((unsigned)threads);
 #define X265AMD_INTRA_SHAPES(KERNEL, NN, ...)                                                              \
     switch (threads) {                                                                                     \
@@ -654,8 +653,14 @@ static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st
     return hip_status(hipGetLastError());
 }
 
-extern "C" void x265amd_debug_intra_fused(int on) { g_intra_fused = on; }
-extern "C" void x265amd_debug_intra_threads(int threads) { g_intra_threads = threads == 256 || threads == 512 || threads == 1024 ? threads : 0; }
+extern "C" void x265amd_debug_intra_fused(int on)
+{
+    if (device_state()) debug_state().intra_fused = on;
+}
+extern "C" void x265amd_debug_intra_threads(int threads)
+{
+    if (device_state()) debug_state().intra_threads = threads == 256 || threads == 512 || threads == 1024 ? threads : 0;
+}
 
 extern "C" int x265amd_intra_waves(const x265amd_intra_frame *f)
 {
@@ -717,7 +722,8 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
                                  (!f->d_abs_sum_u || f->d_abs_sum_v - f->d_abs_sum_u == (int64_t)b.nframes * b.fs_cu);
         if (plane_major) {
             tu.nframes = 2 * b.nframes;
-        } else if (b.fs_c % du == 0 && b.fs_c / du >= 2 && b.fs_c / du < 65536 && tq_takes_mfma(&tu)) {
+        } else if (b.fs_c % du == 0 && b.fs_c / du >= 2 && b.fs_c / du < 65536 && (int64_t)b.nframes * 2 <= 65535 &&
+                   tq_takes_mfma(&tu)) {  // (plane groups are the grid's y: above 32767 frames U and V go separately)
             // frame buffers one after the other (4:2:0: a frame is six chroma-plane sizes long): plane j of frame g is
             // du * (g * fmul + j) behind the first U plane
             pair.fgroup = 2;
@@ -740,7 +746,7 @@ static int intra_encode(const x265amd_intra_frame *f, const IntraBatch &b, hipSt
     // tiles (blocks of later steps come out as garbage until their own step), which is harmless between launches but
     // not inside one.  The CUs of a tile are on diagonals d0 + i + 2 l, i, l < 32 / block: distinct for blocks of 32
     // and of 16 (CU 32: luma 32, chroma 16), not for the 8x8 chroma blocks of CU 16 (i = 2, l = 0 meets i = 0, l = 1).
-    const bool fused_ok = one_launch && g_intra_fused && f->cu == 32;
+    const bool fused_ok = one_launch && debug_state().intra_fused && f->cu == 32;
     IntraTq fused;
     fused.cby_mul = b.nframes == 1 ? 0 : pair.fgroup ? 2 : 1;
     fused.cby_add = b.nframes == 1 || pair.fgroup ? 1 : b.nframes;

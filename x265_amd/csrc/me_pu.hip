@@ -312,7 +312,7 @@ extern "C" int x265amd_me_fullsearch_pu_all(const uint8_t *d_cur, const uint8_t 
     }
     if (!any) return X265AMD_ERR_ARG;
     if (width <= 0 || height <= 0 || width % 64 || height % 64 || stride < width) return X265AMD_ERR_ARG;
-    if (range < 0 || range > 181 || nframes < 0 || nrefs < 1) return X265AMD_ERR_ARG;  // (2 range + 1)^2 <= 2^17: the keys
+    if (range < 0 || range > 180 || nframes < 0 || nrefs < 1) return X265AMD_ERR_ARG;  // (2 range + 1)^2 = 361^2 <= 2^17: the keys
     if ((stride & 3) || ((uintptr_t)d_cur & 3) || ((uintptr_t)d_ref & 3) || (cur_frame_stride & 3) ||
         (ref_frame_stride & 3) || (ref_ref_stride & 3))
         return X265AMD_ERR_ARG;

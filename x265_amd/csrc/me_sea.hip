@@ -1151,37 +1151,41 @@ int me_sea_device_setup(DeviceState &ds)
 
 using namespace x265amd;
 
-// ---- debugging aids (include/x265_amd_debug.h; process-global, one device, one thread) ----
-static uint32_t *g_me_stats = nullptr;
+// ---- debugging aids (include/x265_amd_debug.h): state of the device current on the calling thread ----
 // 16 u32 per CTU; [0] / [1] = groups evaluated in pass 0 / 1; switches both kernels to their stats variants
-extern "C" void x265amd_debug_set_me_stats(uint32_t *d_stats) { g_me_stats = d_stats; }
+extern "C" void x265amd_debug_set_me_stats(uint32_t *d_stats)
+{
+    if (device_state()) debug_state().me_stats = d_stats;
+}
 
 // per-kernel HIP-event timing of the last _sea call on its own stream.  bench.py uses it so that the
 // roofline line can name each kernel's duration without a profiler attached.
-static bool g_me_timing = false;
-static hipEvent_t g_me_ev[5];
 extern "C" int x265amd_debug_me_timing(int enable)
 {
-    if (enable && !g_me_ev[0])
-        for (auto &e : g_me_ev) X265AMD_HIP(hipEventCreate(&e));
-    g_me_timing = enable != 0;
+    if (!device_state()) return X265AMD_ERR_NOT_INIT;
+    DebugState &dbg = debug_state();
+    if (enable && !dbg.me_ev[0])
+        for (auto &e : dbg.me_ev) X265AMD_HIP(hipEventCreate(&e));
+    dbg.me_timing = enable != 0;
     return X265AMD_OK;
 }
 // ms of box16_pairs, (nothing), sea_bounds_kernel, sea_exact_kernel of the last timed call (waits for it)
 extern "C" int x265amd_debug_me_last_ms(float *out4)
 {
-    if (!g_me_ev[0] || !out4) return X265AMD_ERR_ARG;
-    X265AMD_HIP(hipEventSynchronize(g_me_ev[4]));
-    for (int i = 0; i < 4; i++) X265AMD_HIP(hipEventElapsedTime(&out4[i], g_me_ev[i], g_me_ev[i + 1]));
+    if (!device_state()) return X265AMD_ERR_NOT_INIT;
+    DebugState &dbg = debug_state();
+    if (!dbg.me_ev[0] || !out4) return X265AMD_ERR_ARG;
+    X265AMD_HIP(hipEventSynchronize(dbg.me_ev[4]));
+    for (int i = 0; i < 4; i++) X265AMD_HIP(hipEventElapsedTime(&out4[i], dbg.me_ev[i], dbg.me_ev[i + 1]));
     return X265AMD_OK;
 }
 // shape experiments of the exact kernel (A/B runs of tools/): extra dynamic LDS per workgroup, forced wave count
 // (0 = the library's own choice)
-static int g_sea_lds_pad = 0, g_sea_waves = 0;
 extern "C" void x265amd_debug_sea_shape(int lds_pad_bytes, int waves)
 {
-    g_sea_lds_pad = lds_pad_bytes > 0 ? lds_pad_bytes : 0;
-    g_sea_waves = waves;
+    if (!device_state()) return;
+    debug_state().sea_lds_pad = lds_pad_bytes > 0 ? lds_pad_bytes : 0;
+    debug_state().sea_waves = waves;
 }
 
 // largest per-CTU geometry of a picture: rows / pitch of the window, groups per row, rows of candidates
@@ -1250,7 +1254,7 @@ static int launch_exact(DeviceState &ds, size_t lds, hipStream_t st, const uint8
                         const uint32_t *order, uint32_t *ctrl, int total, x265amd_mv *d_out, const MeGeom &g, int gl_pitch,
                         int win_dwords, int surv_off, int surv_cap)
 {
-    uint32_t *const stats = g_me_stats;  // read once: the variant and its argument must agree
+    uint32_t *const stats = ds.dbg.me_stats;  // read once: the variant and its argument must agree
     const void *fn = stats ? (const void *)sea_exact_kernel<true, WAVES, B> : (const void *)sea_exact_kernel<false, WAVES, B>;
     int per_cu = 0;
     const int ost = exact_per_cu(ds, fn, WAVES * 64, lds, per_cu);
@@ -1297,11 +1301,11 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     // otherwise ONE 16-wave workgroup per CU (window + kept list, 32 KB of partial sums, schedule in the workspace)
     constexpr int kSurv8 = 512;  // kept groups of an 8-wave workgroup: two half rounds' worth, 18 bytes each
     const size_t surv8_off = (((size_t)win_dwords * 4 + list_bytes + 15) & ~(size_t)15);
-    const size_t lds8 = surv8_off + (size_t)kSurv8 * 18 + (size_t)g_sea_lds_pad;
+    const size_t lds8 = surv8_off + (size_t)kSurv8 * 18 + (size_t)ds.dbg.sea_lds_pad;
     size_t lds16 = (size_t)win_dwords * 4;
     const size_t lds_cap = (size_t)ds.lds_limit;
     bool waves16 = 2 * (lds8 + 17408) > lds_cap;
-    if (g_sea_waves) waves16 = g_sea_waves == 16;
+    if (ds.dbg.sea_waves) waves16 = ds.dbg.sea_waves == 16;
     if (waves16 && lds16 + 33792 > lds_cap) waves16 = false;
     // 16-wave shape: what is left of the LDS holds the groups that outlive the upper half of the block in the second
     // pass (18 bytes each; at least two half rounds' worth = 1024, else the second pass runs whole rounds)
@@ -1336,7 +1340,9 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     const int total = (int)(nctu * (size_t)nplanes);
 
     hipStream_t st = (hipStream_t)stream;
-    const bool timing = g_me_timing;
+    const bool timing = ds.dbg.me_timing;
+    hipEvent_t *const g_me_ev = ds.dbg.me_ev;
+    uint32_t *const bounds_stats = ds.dbg.me_stats;
     if (timing) (void)hipEventRecord(g_me_ev[0], st);
     const int S = ctu / 4;  // sub-block side: rows y of the pair plane exist for y + S <= height
     const dim3 box_grid((width + kBoxTW - 1) / kBoxTW, (height - (S - 1) + kBoxTH - 1) / kBoxTH, (unsigned)nplanes);
@@ -1361,10 +1367,10 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     g.ref_rs = ref_ref_stride;
     if (ctu == 64)
         hipLaunchKernelGGL(sea_bounds_kernel<64>, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
-                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, g_me_stats);
+                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, bounds_stats);
     else
         hipLaunchKernelGGL(sea_bounds_kernel<32>, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
-                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, g_me_stats);
+                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, bounds_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;

@@ -15,7 +15,13 @@ DeviceState *device_state()
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
     DeviceState *ds = &g_dev[dev];
-    return ds->init ? ds : nullptr;  // `init` is set last, under the lock, and never cleared
+    return ds->init.load(std::memory_order_acquire) ? ds : nullptr;  // stored last by x265amd_init, never cleared
+}
+DebugState &debug_state()
+{
+    static DebugState defaults;  // never written: the setters return early without a device
+    DeviceState *ds = device_state();
+    return ds ? ds->dbg : defaults;
 }
 int lds_limit_bytes()
 {
@@ -52,7 +58,7 @@ extern "C" int x265amd_init(int device)
     if (device < 0 || device >= n || device >= kMaxDevices) return X265AMD_ERR_NO_DEVICE;
     X265AMD_HIP(hipSetDevice(device));
     DeviceState &ds = g_dev[device];
-    if (ds.init) return X265AMD_OK;  // idempotent; the device is current on this thread now
+    if (ds.init.load(std::memory_order_acquire)) return X265AMD_OK;  // idempotent; the device is current on this thread now
     hipDeviceProp_t prop;
     X265AMD_HIP(hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return X265AMD_ERR_ARCH;  // kernels are built for gfx950 only
@@ -66,7 +72,14 @@ extern "C" int x265amd_init(int device)
     if (st == X265AMD_OK) st = me_pu_device_setup(ds);
     if (st == X265AMD_OK) st = me_sea_device_setup(ds);
     if (st != X265AMD_OK) return st;
-    ds.init = true;
+    if (!ds.host_word) {
+        void *hp = nullptr, *dp = nullptr;
+        X265AMD_HIP(hipHostMalloc(&hp, 64, hipHostMallocMapped));
+        X265AMD_HIP(hipHostGetDevicePointer(&dp, hp, 0));
+        ds.host_word = (uint32_t *)hp;
+        ds.host_word_dev = (uint32_t *)dp;
+    }
+    ds.init.store(true, std::memory_order_release);  // everything above is visible to a thread that sees it
     return X265AMD_OK;
 }
 

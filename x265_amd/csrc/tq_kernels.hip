@@ -398,10 +398,18 @@ static void quant_constants(int tu, int qp, int slice_type, TqParams &p)
     }
 }
 
-// debugging aid (include/x265_amd_debug.h): 0 = the library's choice, 1 = always the butterfly kernel
-static int g_tq_path = 0;
-static unsigned long long *g_tq_trace = nullptr;
-static int g_tq_trace_waves = 0;
+// X265AMD_TQ_CHECK_MV: does every vector keep its block inside the prediction plane?  One thread per vector.
+__global__ __launch_bounds__(256) void mv_check_kernel(const x265amd_mv *__restrict__ mv, int64_t frame_stride, int per_frame,
+                                                       int ctus_x, int mv_ctu, int shift, int width, int height, int nframes,
+                                                       uint32_t *__restrict__ verdict)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)per_frame * nframes) return;
+    const int f = (int)(i / per_frame), k = (int)(i - (int64_t)f * per_frame);
+    const x265amd_mv v = mv[(int64_t)f * frame_stride + k];
+    const int x = (k % ctus_x) * mv_ctu + (v.mvx >> shift), y = (k / ctus_x) * mv_ctu + (v.mvy >> shift);
+    if (x < 0 || y < 0 || x + mv_ctu > width || y + mv_ctu > height) atomicOr(verdict, 1u);
+}
 
 // validation + the kernels' parameter block; `empty`: nothing to launch (nframes = 0)
 template <int MODE> static int tq_build(const x265amd_tq_desc *desc, bool coef_in, const TqDiag *diag, TqParams &p, bool &empty)
@@ -421,6 +429,7 @@ template <int MODE> static int tq_build(const x265amd_tq_desc *desc, bool coef_i
                    d.mv_ctu % d.tu))
         return X265AMD_ERR_ARG;
     if (d.mv_shift < 0 || d.mv_shift > 3) return X265AMD_ERR_ARG;
+    if (d.flags & ~X265AMD_TQ_CHECK_MV) return X265AMD_ERR_ARG;
     // strides: a row must hold the picture (a zero-initialised stride would make every row alias); outputs of a
     // batch need their own planes.  With d_mv the prediction plane is addressed relative to d_pred in both
     // directions (vectors), so only its sign is checked.
@@ -447,8 +456,8 @@ template <int MODE> static int tq_build(const x265amd_tq_desc *desc, bool coef_i
     quant_constants(d.tu, d.qp, d.slice_type, p);
     p.mv_ctu_log2 = d.d_mv ? ilog2(d.mv_ctu) : 0;
     p.mv_ctus_x = d.d_mv ? d.width / d.mv_ctu : 0;
-    p.d_trace = g_tq_trace;
-    p.trace_waves = g_tq_trace_waves;
+    p.d_trace = debug_state().tq_trace;
+    p.trace_waves = debug_state().tq_trace_waves;
     p.diag_count = 0;
     p.diag_d = p.diag_lo = p.diag_cu_log2 = 0;
     p.diag_fgroup = p.diag_fmul = 0;
@@ -477,6 +486,19 @@ template <int MODE> static int launch_tq(const x265amd_tq_desc *desc, hipStream_
     const int st = tq_build<MODE>(desc, coef_in, diag, p, empty);
     if (st != X265AMD_OK || empty) return st;
     const x265amd_tq_desc &d = p.d;
+    if (d.d_mv && (d.flags & X265AMD_TQ_CHECK_MV)) {
+        DeviceState *ds = device_state();
+        if (!ds || !ds->host_word) return X265AMD_ERR_NOT_INIT;
+        std::lock_guard<std::mutex> lk(state_mutex());  // one verdict word per device
+        *ds->host_word = 0u;
+        const int per_frame = (d.width / d.mv_ctu) * (d.height / d.mv_ctu);
+        const int64_t nvec = (int64_t)per_frame * d.nframes;
+        hipLaunchKernelGGL(mv_check_kernel, dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, stream, d.d_mv, d.mv_frame_stride,
+                           per_frame, d.width / d.mv_ctu, d.mv_ctu, d.mv_shift, d.width, d.height, d.nframes, ds->host_word_dev);
+        X265AMD_HIP(hipGetLastError());
+        X265AMD_HIP(hipStreamSynchronize(stream));
+        if (*(volatile uint32_t *)ds->host_word) return X265AMD_ERR_ARG;  // a vector leaves the plane: nothing was transformed
+    }
     const int64_t nt = p.ntiles;
     // the matrix-core formulation (tq_mfma.hip) wherever the transform matrix is the same for every TU of the
     // plane and the rows split into 16-byte pieces; per-TU DST selection at 4x4 (d_modes), widths that are not a
@@ -500,7 +522,7 @@ bool tq_takes_mfma(const x265amd_tq_desc *desc)
     const int kLim = 1 << 23;
     const bool small = d.height < kLim && d.level_stride < kLim && d.pred_stride < kLim && d.src_stride < kLim &&
                        d.rec_stride < kLim;
-    return g_tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0 && small;
+    return debug_state().tq_path != 1 && !(d.tu == 4 && d.d_modes) && d.width % 16 == 0 && small;
 }
 
 int tq_diag_yuv_params(const x265amd_tq_desc *luma, const TqDiag &dl, const x265amd_tq_desc *chroma, const TqDiag &dc, TqParams &py,
@@ -533,11 +555,15 @@ int tq_roundtrip_diag(const x265amd_tq_desc *desc, const TqDiag &diag, hipStream
 
 using namespace x265amd;
 
-extern "C" void x265amd_debug_tq_path(int path) { g_tq_path = path; }
+extern "C" void x265amd_debug_tq_path(int path)
+{
+    if (device_state()) debug_state().tq_path = path;
+}
 extern "C" void x265amd_debug_tq_trace(unsigned long long *d_records, int nwaves)
 {
-    g_tq_trace = d_records;
-    g_tq_trace_waves = d_records ? nwaves : 0;
+    if (!device_state()) return;
+    debug_state().tq_trace = d_records;
+    debug_state().tq_trace_waves = d_records ? nwaves : 0;
 }
 
 extern "C" int x265amd_tq_forward(const x265amd_tq_desc *desc, void *stream)

@@ -65,8 +65,10 @@ template <int MODE> static void launch_mv(dim3 grid, hipStream_t stream, const T
 
 // Units per workgroup.  0 = an even split over the workgroups the chip holds at once (four per CU: four waves per
 // SIMD); n > 0 = n units per workgroup, the dispatcher handing out workgroups as others finish.
-static int g_units_per_wg = 0;
-extern "C" void x265amd_debug_tq_units_per_wg(int n) { g_units_per_wg = n < 0 ? 0 : n; }
+extern "C" void x265amd_debug_tq_units_per_wg(int n)
+{
+    if (device_state()) debug_state().tq_units_per_wg = n < 0 ? 0 : n;
+}
 
 int launch_tq_mfma(int mode, const TqParams &p_in, hipStream_t stream)
 {
@@ -76,7 +78,8 @@ int launch_tq_mfma(int mode, const TqParams &p_in, hipStream_t stream)
     if (units > 0x7fffffff) return X265AMD_ERR_ARG;
     const int64_t resident = (int64_t)cu_count() * kWgPerCu;
     int64_t nwg = units < resident ? units : resident;
-    if (g_units_per_wg > 0) nwg = (units + g_units_per_wg - 1) / g_units_per_wg;
+    const int units_per_wg = debug_state().tq_units_per_wg;
+    if (units_per_wg > 0) nwg = (units + units_per_wg - 1) / units_per_wg;
     dim3 grid((unsigned)nwg);
     if (p.diag_count > 0) {
         // every CU of the diagonal must lie inside the plane: the kernel takes its unit from the CU's position

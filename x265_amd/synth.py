@@ -108,6 +108,44 @@ def make_sequence(width, height, nframes, search_range=64, seed=12345, chroma=Fa
     return luma
 
 
+def make_textured_sequence(width, height, nframes, search_range=64, ctu=64, seed=777):
+    """A third content class beside the smooth sequence and white noise: 1/f-like texture (seven octaves of LCG
+    value noise from 128- to 2-pixel cells, bilinearly interpolated, amplitude x 0.7 per octave) in which EVERY ctu x ctu block of a frame
+    moves with its own vector -- frame n is cut from frame 0 block by block, the vectors drawn from the LCG in
+    [-R/2, R/2]^2 (clamped to the picture), plus fresh 2-bit noise.  Bounds prune part of the candidates here,
+    neither nearly all (the smooth sequence) nor none (white noise).  Returns luma uint8[nframes][height][width]."""
+    g = LCG(seed)
+    acc = np.zeros((height, width), np.float32)
+    amp = 48.0
+    for octave in range(7):
+        cell = 128 >> octave                        # 128, 64, .. 2 pixels per lattice cell
+        gh, gw = height // cell + 2, width // cell + 2
+        lat = ((g.take(gh * gw) >> np.uint32(24)).astype(np.float32) / 255.0 - 0.5).reshape(gh, gw)
+        yy = np.arange(height, dtype=np.float32) / cell
+        xx = np.arange(width, dtype=np.float32) / cell
+        y0, x0 = yy.astype(np.int32), xx.astype(np.int32)
+        fy, fx = (yy - y0)[:, None], (xx - x0)[None, :]
+        a = lat[y0][:, x0] * (1 - fx) + lat[y0][:, x0 + 1] * fx
+        b = lat[y0 + 1][:, x0] * (1 - fx) + lat[y0 + 1][:, x0 + 1] * fx
+        acc += amp * (a * (1 - fy) + b * fy)
+        amp *= 0.7
+    base = np.clip(np.rint(acc + 128.0), 0, 255).astype(np.uint8)
+    luma = np.empty((nframes, height, width), np.uint8)
+    luma[0] = base
+    half = search_range // 2
+    for n in range(1, nframes):
+        f = np.empty((height, width), np.uint32)
+        for by in range(0, height, ctu):
+            for bx in range(0, width, ctu):
+                bh, bw = min(ctu, height - by), min(ctu, width - bx)
+                dx = min(max(bx + g.next_int(-half, half), 0), width - bw) - bx
+                dy = min(max(by + g.next_int(-half, half), 0), height - bh) - by
+                f[by:by + bh, bx:bx + bw] = base[by + dy:by + dy + bh, bx + dx:bx + dx + bw]
+        f += (g.take(width * height) >> np.uint32(24)).reshape(height, width) & np.uint32(3)
+        luma[n] = np.minimum(f, 255).astype(np.uint8)
+    return luma
+
+
 def make_intra_probe(width, height, nframes, seed=12345):
     """The SURVEY.md App. B whole-encoder probe input (BASELINE.json configs[0]):
     LCG state carried across frames; Y = u8(((x+2n)*3 + (y+n)*2)/4 + ((s>>24)&15)),
