@@ -184,7 +184,7 @@ __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est
 //        list0[plane][ctu][..] the first batch (the kFirst groups of the lowest histogram bins), hdr
 // ---------------------------------------------------------------------------------------------
 template <int B>
-__global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
+__global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
                                                                    const uint8_t *__restrict__ ref_base,
                                                                  const uint32_t *__restrict__ pbuf,
                                                                  uint16_t *__restrict__ gl, uint16_t *__restrict__ list0,
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     __shared__ int list_n, eq_n, pick_bin, below_n, est_n;
     __shared__ uint32_t min_key, max_st, probe_sad, probe_idx, pref[kBins];
     __shared__ uint32_t rest_lb;
-    __shared__ uint32_t bank_cnt[32];
+    __shared__ uint32_t bank_cnt[32], rank_base[64], rank_mask[64];
     __shared__ uint16_t sel_ent[kFirst];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -402,10 +402,9 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
     const int quota = kFirst - nbelow;     // list0[nbelow .. nbelow + min(quota, |bin pb|)) = bin pb
 
     const long long tb3 = stats ? clock64() : 0;
-    // ---- write the bounds out; groups of the first batch go to list0 (scan order within a wave) and
-    //      are marked; the smallest bound left over goes to the header ----
-    // A thread takes 8 consecutive groups (one 16-byte LDS read, one 16-byte store); a wave reserves its
-    // list slots with ONE LDS atomic per counter per sweep.
+    // ---- the first batch is picked out of the bounds in LDS -- a lane per group, consecutive groups to consecutive
+    //      lanes, a wave reserves its list slots with ONE LDS atomic per counter per sweep -- and marked there; the
+    //      smallest bound left over goes to the header.  Then the bounds go out as they stand, 16 bytes per lane. ----
     uint16_t *glo = gl + ctu_id * gl_pitch;
     uint16_t *lo = list0 + ctu_id * gl_pitch;
     uint32_t rest_min = kNone;
@@ -459,64 +458,38 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
             probe_idx = (uint32_t)ubk;
         }
     } else
-    for (int v0 = 0; v0 < nvec; v0 += kBoundsThreads - 64) {
-        if (v0 + (wtid & ~63) >= nvec) break;  // nothing left for this wave (wave-uniform; no barrier inside)
-        const int vi = v0 + wtid;
-        uint4 wv = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-        if (vi < nvec) wv = reinterpret_cast<const uint4 *>(glb)[vi];
-        uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
-        uint32_t lom = 0, eqm = 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint32_t v = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-            const bool valid = vi < nvec && 8 * vi + e < L.ngroups && v != kNone;
-            const int bin = valid ? lb_bin(v) : kBins + 1;
-            if (bin < pb) lom |= 1u << e;                 // pb == kBins: every legal group
-            if (bin == pb && pb < kBins) eqm |= 1u << e;
-            if (!valid) w[e >> 1] |= 0xffffu << (16 * (e & 1));  // what lies past the last group reads as kNone
-        }
-        // inclusive wave scan of (taken below pb | in pb << 16)
-        const uint32_t cnt = (uint32_t)__popc(lom) | ((uint32_t)__popc(eqm) << 16);
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
-        }
-        const uint32_t tot = __shfl(inc, 63);
+    for (int g0 = 0; g0 < L.ngroups; g0 += kBoundsThreads - 64) {
+        if (g0 + (wtid & ~63) >= L.ngroups) break;  // nothing left for this wave (wave-uniform; no barrier inside)
+        const int gi = g0 + wtid;
+        const uint32_t v = gi < L.ngroups ? (uint32_t)glb[gi] : kNone;
+        const bool valid = v != kNone;
+        const int bin = valid ? lb_bin(v) : kBins + 1;
+        const bool below = bin < pb;                   // pb == kBins: every legal group
+        const bool equal = bin == pb && pb < kBins;
+        const unsigned long long mb = __ballot(below), me = __ballot(equal);
         int wl = 0, we = 0;
         if (lane == 0) {
-            if (tot & 0xffffu) wl = atomicAdd(&list_n, (int)(tot & 0xffffu));
-            if (tot >> 16) we = atomicAdd(&eq_n, (int)(tot >> 16));
+            if (mb) wl = atomicAdd(&list_n, __popcll(mb));
+            if (me) we = atomicAdd(&eq_n, __popcll(me));
         }
-        int sl = __shfl(wl, 0) + (int)((inc - cnt) & 0xffffu);          // next slot among the groups under pb
-        int se = __shfl(we, 0) + (int)((inc - cnt) >> 16);              // rank within bin pb
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int gi = 8 * vi + e;
-            bool take = false;
-            int slot = 0;
-            if (lom & (1u << e)) {
-                take = true;
-                slot = sl++;
-            } else if (eqm & (1u << e)) {
-                take = se < quota;
-                slot = nbelow + se++;
-            }
-            const uint32_t v = (w[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-            if (take) {
-                sel_ent[slot] = (uint16_t)gi;  // schedule entry = the group's index dyi * ngx + gx
-                w[e >> 1] |= 0xffffu << (16 * (e & 1));  // scheduled: kNone
-            } else if (v != kNone) {
-                rest_min = min(rest_min, v);
-            }
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        const int sl = __shfl(wl, 0) + __popcll(mb & lt);  // next slot among the groups under pb
+        const int se = __shfl(we, 0) + __popcll(me & lt);  // rank within bin pb (both read lane 0: outside any branch)
+        const bool take = below || (equal && se < quota);
+        const int slot = equal ? nbelow + se : sl;
+        if (take) {
+            sel_ent[slot] = (uint16_t)gi;  // schedule entry = the group's index dyi * ngx + gx
+            glb[gi] = (uint16_t)kNone;     // scheduled
+        } else if (valid) {
+            rest_min = min(rest_min, v);
         }
-        if (vi < nvec) reinterpret_cast<uint4 *>(glo)[vi] = make_uint4(w[0], w[1], w[2], w[3]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rest_min = min(rest_min, (uint32_t)__shfl_xor((int)rest_min, o));
     if (lane == 0 && rest_min != kNone) atomicMin(&rest_lb, rest_min);
     __syncthreads();
+    // (what lies past a block's last group in its last 16 bytes is never looked at: kernel 2 checks the index)
+    for (int vi = tid; vi < nvec; vi += kBoundsThreads) reinterpret_cast<uint4 *>(glo)[vi] = reinterpret_cast<const uint4 *>(glb)[vi];
     // ---- order the first batch for kernel 2's LDS reads: a lane there reads window dwords
     //      (dyi + row) * pitch + gx + k, so the 32 lanes of a half wave collide whenever their
     //      dyi * pitch + gx agree mod 32.  Deal the entries out bank by bank (rank within the bank first,
@@ -530,12 +503,35 @@ __global__ __launch_bounds__(kBoundsThreads) void sea_bounds_kernel(const uint8_
         my_rank = (int)atomicAdd(&bank_cnt[my_bank], 1u);
     }
     __syncthreads();
-    if (tid < n0) {
-        int pos = 0;
+    // position of (rank r, bank k) = sum_b min(count_b, r) + #{b < k : count_b > r}: wave 0 tabulates, per rank, the
+    // first term (a running sum of how many banks hold more than r entries) and the banks that do, as a bit mask
+    if (tid < 64) {
+        uint32_t cnt = 0, msk = 0;
 #pragma unroll
         for (int b = 0; b < 32; b++) {
-            const int cb = (int)bank_cnt[b];
-            pos += min(cb, my_rank) + ((b < my_bank && cb > my_rank) ? 1 : 0);
+            const uint32_t gt = bank_cnt[b] > (uint32_t)tid ? 1u : 0u;
+            cnt += gt;
+            msk |= gt << b;
+        }
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        rank_base[tid] = inc - cnt;
+        rank_mask[tid] = msk;
+    }
+    __syncthreads();
+    if (tid < n0) {
+        int pos = 0;
+        if (my_rank < 64) {
+            pos = (int)rank_base[my_rank] + __popc(rank_mask[my_rank] & ((1u << my_bank) - 1u));
+        } else {  // more than 64 entries of one bank: the sum written out
+            for (int b = 0; b < 32; b++) {
+                const int cb = (int)bank_cnt[b];
+                pos += min(cb, my_rank) + ((b < my_bank && cb > my_rank) ? 1 : 0);
+            }
         }
         lo[pos] = (uint16_t)my_ent;
     }
