@@ -36,7 +36,7 @@ def main():
             merged[k].update(v)
     res = {}
     for k, c in sorted(merged.items()):
-        if not k.startswith(("sea_", "box16", "tq_kernel", "tq_mfma", "me_fullsearch", "me_tree", "sad_blocks", "intra_")):
+        if not k.startswith(("sea_", "box16", "tq_kernel", "tq_mfma", "me_fullsearch", "me_list_qsad", "me_tree", "sad_blocks", "intra_")):
             continue
         # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs (sea_exact_kernel: 9.9 M for a 0.49 ms kernel = 8 x 1.24 M
         # cycles); the SQ counters are chip totals (SQ_WAVES = every wave of the grid)

@@ -46,7 +46,7 @@ def main():
             "fetch_bytes_x2": fetch.get(k, 0.0) * 2048 / max(nf.get(k, 0), 1),
             "write_bytes": write.get(k, 0.0) * 1024 / max(nw.get(k, 0), 1),
         }
-    me = [k for k in kernels if k.startswith(("sea_", "box16", "me_fullsearch"))]
+    me = [k for k in kernels if k.startswith(("sea_", "box16", "me_fullsearch", "me_list_qsad"))]
     tq = [k for k in kernels if k.startswith(("tq_kernel", "tq_mfma"))]
     entry = {
         "launches": launches,

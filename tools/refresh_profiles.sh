@@ -11,9 +11,10 @@ cd $ROOT
 case "$1" in
 bench)
   timeout -k 10 500 python bench.py > $OUT/bench_1080p.json 2> $OUT/bench_1080p.err; echo "1080p done"
-  for WL in 4k 8k4ref gop1080p; do
-    timeout -k 10 300 python bench.py --workload $WL --no-cpu-baseline > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err; echo "$WL done"
-  done
+  # the other search configurations in full too: statistics pass, CPU sample, in-run parity
+  timeout -k 10 400 python bench.py --workload 4k > $OUT/bench_4k.json 2> $OUT/bench_4k.err; echo "4k done"
+  timeout -k 10 500 python bench.py --workload 8k4ref --steps 20 --warmup 5 > $OUT/bench_8k4ref.json 2> $OUT/bench_8k4ref.err; echo "8k4ref done"
+  timeout -k 10 300 python bench.py --workload gop1080p --no-cpu-baseline > $OUT/bench_gop1080p.json 2> $OUT/bench_gop1080p.err; echo "gop1080p done"
   for TU in 32 16 8 4; do
     timeout -k 10 200 python bench.py --workload tq1080p --tu $TU --steps 50 --warmup 5 --no-cpu-baseline > $OUT/bench_tq1080p_tu$TU.json 2> $OUT/bench_tq_tu$TU.err
   done
@@ -23,6 +24,8 @@ bench)
   timeout -k 10 300 python tools/intra_bench.py > $OUT/intra_bench.txt 2>&1; echo "intra done"
   timeout -k 10 100 python tools/tq_trace.py 32 16 > $OUT/tq_trace.txt 2>&1; echo "tq trace done"
   timeout -k 10 400 bash tools/encode_i_bench.sh > $OUT/encode_i_bench.txt 2>&1; echo "encode_i done"
+  timeout -k 10 100 python tools/sea_stats.py 16 > $OUT/sea_stats.txt 2>&1; echo "sea stats done"
+  timeout -k 10 100 python tools/noise_split.py > $OUT/noise_split.txt 2>&1; echo "noise split done"
   ;;
 trace)
   cd /tmp && export TMPDIR=/tmp
