@@ -188,9 +188,10 @@ def legal_candidates(w, h, ctu, rng):
     return n
 
 
-def evaluated_groups(pipe):
-    """One extra, untimed pass with the statistics variant of the elimination kernels: groups of four
-    candidates that got an exact SAD (first batch + second pass), summed over the batch."""
+def evaluated_half_groups(pipe):
+    """One extra, untimed pass with the statistics variant of the elimination kernels: HALF blocks of groups of four
+    candidates whose SAD was evaluated (upper halves of everything scheduled + the lower halves that were finished),
+    summed over the batch."""
     lib = x265_amd.api._lib()
     stats = torch.zeros((pipe.nframes * pipe.nrefs, pipe.nctu, 16), dtype=torch.int32, device="cuda")
     lib.x265amd_debug_set_me_stats(stats.data_ptr())
@@ -200,7 +201,9 @@ def evaluated_groups(pipe):
     finally:
         lib.x265amd_debug_set_me_stats(None)
     s = stats.cpu().numpy().astype(np.int64)
-    return int(s[..., 0].sum() + s[..., 1].sum())
+    # half blocks: every scheduled group's upper half ([0] first batch, [1] second pass) + the lower halves that were
+    # finished ([15], [14]); a second pass of at most 64 groups goes whole and is counted in both
+    return int(s[..., 0].sum() + s[..., 1].sum() + s[..., 14].sum() + s[..., 15].sum())
 
 
 def kernel_split(pipe, reps):
@@ -615,8 +618,8 @@ def search_and_tq(args, grp, nw, nh, ctu, rng, nrefs, fps, tu, qp):
                 "exhaustive_pixel_sads_per_launch": exhaustive,
                 "exhaustive_equivalent_Tpx_sad_per_s": round(exhaustive / (me_ms * 1e-3) / 1e12, 3)}
         if pipe.method == "sea" and not args.lean:
-            groups = evaluated_groups(pipe)
-            ev_sads = groups * 4 * ctu * ctu         # a group = four candidates, each a full 64x64 SAD
+            halves = evaluated_half_groups(pipe)
+            ev_sads = halves * 4 * ctu * ctu // 2    # a group = four candidates, half a block = ctu x ctu / 2 pixels each
             valu.update({
                 "evaluated_pixel_sads_per_launch": ev_sads,
                 "evaluated_fraction_of_exhaustive": round(ev_sads / exhaustive, 5),
@@ -625,7 +628,8 @@ def search_and_tq(args, grp, nw, nh, ctu, rng, nrefs, fps, tu, qp):
                 "frac_exact_kernel_alone": round(ev_sads / (kernels_ms["sea_exact_kernel"] * 1e-3) / 1e12 / QSAD_PEAK_TPX, 4)
                 if kernels_ms else None,
                 "note": "achieved = pixel-SADs the elimination search actually evaluated (statistics variant of the "
-                        "kernels, one extra untimed pass) / search-stage time: the stage's real qsad issue rate against "
+                        "kernels, one extra untimed pass; counted in half blocks: a group dropped after its upper half "
+                        "counts half) / search-stage time: the stage's real qsad issue rate against "
                         "the measured issue peak.  exhaustive_equivalent = what an every-candidate search would have "
                         "had to evaluate / the same time (an effective rate, not a utilisation)"})
         elif pipe.method == "brute":
