@@ -164,13 +164,13 @@ constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or alread
 __device__ __forceinline__ uint32_t lb_store(uint32_t lb) { return lb >> 4; }
 
 struct SeaHdr {  // per (plane, CTU)
-    uint32_t n0_rest;    // low half: groups in the first batch (<= kFirst); high half: smallest stored bound among the
+    uint32_t n0_rest;    // low half: groups in the first batch (<= kFirstMax); high half: smallest stored bound among the
                          // groups NOT in it (kNone: none left)
     uint32_t est;        // work estimate: groups with a bound <= the probed SAD (an upper bound of n0 + second pass)
     uint32_t probe_sad;  // the probe's best candidate: its exact SAD and raster index -- where kernel 2's search starts
     uint32_t probe_idx;  // (0xffffffff / 0xffffffff: no probe)
 };
-constexpr int kFirst = 256;   // first batch: two rounds of 128 groups
+constexpr int kFirstMax = 512;  // first batch = ONE half round of kernel 2: 256 groups for its 8-wave shape, 512 for the 16-wave one
 constexpr int kMaxWgLists = 512;  // persistent workgroups that may need a schedule slice in the workspace
 constexpr int kClasses = 4;   // launch-order classes of the work estimate, heaviest first
 // ctrl[] (8 counters, zeroed by box16_pairs): [0 .. kClasses) lengths of the class queues, [kClasses] next item of kernel 2,
@@ -181,7 +181,7 @@ __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est
 // ---------------------------------------------------------------------------------------------
 // Kernel 1: bounds.  No window, 9 KB of LDS => high occupancy hides the box-sum loads.
 //   out: gl[plane][ctu][max_groups] u16 bound per group (kNone where scheduled / illegal),
-//        list0[plane][ctu][..] the first batch (the kFirst groups of the lowest histogram bins), hdr
+//        list0[plane][ctu][..] the first batch (the `nfirst` groups of the lowest histogram bins), hdr
 // ---------------------------------------------------------------------------------------------
 template <int B>
 __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
                                                                  uint16_t *__restrict__ gl, uint16_t *__restrict__ list0,
                                                                  SeaHdr *__restrict__ hdr, uint32_t *__restrict__ order,
                                                                  uint32_t *__restrict__ ctrl, const MeGeom g, int gl_pitch,
-                                                                 int nplanes, uint32_t *__restrict__ stats)
+                                                                 int nplanes, int nfirst, uint32_t *__restrict__ stats)
 {
     constexpr int S = B / 4;  // side of a sub-block
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
     __shared__ uint32_t min_key, max_st, probe_sad, probe_idx, pref[kBins];
     __shared__ uint32_t rest_lb;
     __shared__ uint32_t bank_cnt[32], rank_base[64], rank_mask[64];
-    __shared__ uint16_t sel_ent[kFirst];
+    __shared__ uint16_t sel_ent[kFirstMax];
 
     const int tid = threadIdx.x, lane = tid & 63;
     // XCD-aware order: workgroup w runs on XCD w % 8 (round-robin dispatch), each XCD has its own L2,
@@ -366,8 +366,8 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
     __syncthreads();
 
     const long long tb2 = stats ? clock64() : 0;
-    // ---- first batch: the kFirst groups of the lowest bins.  pick_bin = the bin in which the running
-    //      count reaches kFirst; below_n = groups in the bins under it (all taken), the rest of the
+    // ---- first batch: the nfirst groups of the lowest bins.  pick_bin = the bin in which the running
+    //      count reaches nfirst; below_n = groups in the bins under it (all taken), the rest of the
     //      quota comes from pick_bin itself, whichever of its groups the scan reaches first ----
     if (tid < 64) {
         uint32_t c0 = hist[tid], c1 = (tid + 64 < kBins) ? hist[tid + 64] : 0u;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
             if (lane >= o) s1 += t;
         }
         s1 += tot0;
-        const unsigned long long m0 = __ballot(s0 >= (uint32_t)kFirst), m1 = __ballot(s1 >= (uint32_t)kFirst && tid + 64 < kBins);
+        const unsigned long long m0 = __ballot(s0 >= (uint32_t)nfirst), m1 = __ballot(s1 >= (uint32_t)nfirst && tid + 64 < kBins);
         const int pbv = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : kBins);
         const uint32_t incl = pbv < 64 ? __shfl(s0, pbv & 63) : __shfl(s1, pbv & 63);  // count through pick_bin
         const uint32_t own = pbv < 64 ? __shfl(c0, pbv & 63) : __shfl(c1, pbv & 63);
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
     __syncthreads();
     const int pb = pick_bin;
     const int nbelow = below_n;            // list0[0 .. nbelow) = bins < pb
-    const int quota = kFirst - nbelow;     // list0[nbelow .. nbelow + min(quota, |bin pb|)) = bin pb
+    const int quota = nfirst - nbelow;     // list0[nbelow .. nbelow + min(quota, |bin pb|)) = bin pb
 
     const long long tb3 = stats ? clock64() : 0;
     // ---- the first batch is picked out of the bounds in LDS -- a lane per group, consecutive groups to consecutive
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *win = smem;                                                     // [win_rows][pitch] reference window
     constexpr int kThreads = WAVES * 64, kHalf = 32 * WAVES;  // groups of a half round: WAVES / 2 sets of 64
-    static_assert(kFirst <= kHalf, "the first batch is one half round");
+    static_assert(kFirstMax <= 32 * 16 && kBoundsThreads >= kFirstMax, "the first batch is one half round; kernel 1 deals it a thread per entry");
     // second-pass schedule: in LDS behind the window (8 waves), or in this workgroup's own slice of the
     // workspace when the LDS is needed for a +-128 window and 16 waves' partial sums (same-CU L1: coherent
     // across the barrier for the waves of one workgroup)
@@ -1363,10 +1363,10 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     g.ref_rs = ref_ref_stride;
     if (ctu == 64)
         hipLaunchKernelGGL(sea_bounds_kernel<64>, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
-                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, bounds_stats);
+                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, waves16 ? 512 : 256, bounds_stats);
     else
         hipLaunchKernelGGL(sea_bounds_kernel<32>, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
-                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, bounds_stats);
+                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, waves16 ? 512 : 256, bounds_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;
