@@ -748,6 +748,29 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
 
     // ---- stage the reference window: a wave per row, a lane per dword, 13 rows in flight ----
     constexpr int kWinInFlight = 13;
+    if (WAVES == 16 && L.pitch > 64) {  // (the 8-wave shape never sees such a window: it would not fit twice into the LDS)
+        // a row wider than a wave (+-128: 83 dwords): the window as ONE run of win_rows x pitch dwords dealt over the whole
+        // workgroup, so that no load instruction goes out with a quarter of its lanes (a second column pass would)
+        const int total_dw = L.win_rows * L.pitch;
+        const uint32_t recip = 0xffffffffu / (uint32_t)L.pitch + 1u;  // e / pitch = (e * recip) >> 32 for e < 2^16 x pitch
+        for (int e0 = tid; e0 < total_dw; e0 += kThreads * kWinInFlight) {
+            uint32_t v[kWinInFlight];
+#pragma unroll
+            for (int j = 0; j < kWinInFlight; j++) {
+                const int e = e0 + kThreads * j;
+                const int row = (int)__umulhi((uint32_t)e, recip), wq = e - row * L.pitch;
+                const int gx = L.wx0 + 4 * wq, gy = cy + L.dylo + row;
+                v[j] = 0;
+                if (e < total_dw && gx + 4 <= g.width && gy < g.height)
+                    v[j] = *reinterpret_cast<const uint32_t *>(ref + (int64_t)gy * g.stride + gx);
+            }
+#pragma unroll
+            for (int j = 0; j < kWinInFlight; j++) {
+                const int e = e0 + kThreads * j;
+                if (e < total_dw) win[e] = v[j];
+            }
+        }
+    } else
     for (int qb = 0; qb < L.pitch; qb += 64) {
         const int wq = qb + lane;
         const int gx = L.wx0 + 4 * wq;
