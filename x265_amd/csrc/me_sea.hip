@@ -976,13 +976,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     const unsigned long long bk0 = best_key;
     const uint32_t best_sad = (uint32_t)(bk0 >> 32), best_idx = (uint32_t)bk0;
     if (rest_min != kNone && (rest_min << 4) <= best_sad) {
-        // one sweep: a thread takes 8 consecutive bounds (one 16-byte load, all of a CTU's loads in flight at
-        // once), a wave scan ranks the takers, ONE LDS atomic per wave reserves their slots
+        // one sweep: a thread takes 2 x 8 consecutive bounds (two 16-byte loads, all of a CTU's loads in flight at
+        // once); a wave without a taker is done; in the others a wave scan ranks the takers and ONE LDS atomic per
+        // wave reserves their slots
         const int nvec = (L.ngroups + 7) >> 3;  // gl rows are 16-byte aligned and padded to a multiple of 8
-        for (int v0 = 0; v0 < nvec; v0 += kThreads) {
-            const int vi = v0 + tid;
-            uint4 wv = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-            if (vi < nvec) wv = reinterpret_cast<const uint4 *>(glo)[vi];
+        auto takers = [&](const uint4 wv, int vi) __attribute__((always_inline)) -> uint32_t {
             const uint32_t w[4] = {wv.x, wv.y, wv.z, wv.w};
             uint32_t tm = 0;
 #pragma unroll
@@ -998,7 +996,16 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                     if (take) tm |= 1u << e;
                 }
             }
-            const int cnt = __popc(tm);
+            return tm;
+        };
+        for (int v0 = 0; v0 < nvec; v0 += 2 * kThreads) {
+            const int vi0 = v0 + tid, vi1 = vi0 + kThreads;
+            uint4 wv0 = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu), wv1 = wv0;
+            if (vi0 < nvec) wv0 = reinterpret_cast<const uint4 *>(glo)[vi0];
+            if (vi1 < nvec) wv1 = reinterpret_cast<const uint4 *>(glo)[vi1];
+            const uint32_t tm0 = takers(wv0, vi0), tm1 = takers(wv1, vi1);
+            if (__ballot((tm0 | tm1) != 0u) == 0ull) continue;  // wave-uniform
+            const int cnt = __popc(tm0) + __popc(tm1);
             int inc = cnt;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
@@ -1006,13 +1013,15 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                 if (lane >= o) inc += t;
             }
             const int tot = __shfl(inc, 63);
-            if (tot == 0) continue;  // wave-uniform
             int wbase = 0;
             if (lane == 0) wbase = atomicAdd(&list_n, tot);
             int slot = __shfl(wbase, 0) + inc - cnt;
 #pragma unroll
             for (int e = 0; e < 8; e++)
-                if (tm & (1u << e)) list[slot++] = (uint16_t)(8 * vi + e);
+                if (tm0 & (1u << e)) list[slot++] = (uint16_t)(8 * vi0 + e);
+#pragma unroll
+            for (int e = 0; e < 8; e++)
+                if (tm1 & (1u << e)) list[slot++] = (uint16_t)(8 * vi1 + e);
         }
         if (tid == 0) surv_n = 0;
         __syncthreads();
