@@ -21,6 +21,28 @@ def content(rng, kind, f, r, h, w):
     elif kind == "flat":
         cur = np.full((f, h, w), int(rng.integers(0, 256)), np.uint8)
         ref = np.full((f, r, h, w), int(rng.integers(0, 256)), np.uint8)
+    elif kind == "spots":  # flat with a few odd pixels: ties nearly everywhere, decided by raster order
+        cur = np.full((f, h, w), 90, np.uint8)
+        ref = np.full((f, r, h, w), 90, np.uint8)
+        for a_ in (cur, ref):
+            n = int(rng.integers(1, 40))
+            flat = a_.reshape(-1)
+            flat[rng.integers(0, flat.size, n)] = rng.integers(0, 256, n).astype(np.uint8)
+    elif kind == "lowamp":  # two-bit noise: thousands of near ties, bounds close to the SADs' spread
+        cur = rng.integers(0, 4, (f, h, w)).astype(np.uint8)
+        ref = rng.integers(0, 4, (f, r, h, w)).astype(np.uint8)
+    elif kind == "mixed":  # noise on one side of the picture, flat on the other, the references alike
+        cur = rng.integers(0, 256, (f, h, w), dtype=np.uint8)
+        ref = rng.integers(0, 256, (f, r, h, w), dtype=np.uint8)
+        cut = int(rng.integers(1, w))
+        cur[:, :, cut:] = 128
+        ref[:, :, :, max(cut - 32, 0):] = 128
+    elif kind == "repeat":  # a periodic pattern: many exact ties at different displacements
+        px, py = int(rng.integers(2, 24)), int(rng.integers(2, 24))
+        tile = rng.integers(0, 256, (py, px), dtype=np.uint8)
+        big = np.tile(tile, (h // py + 2, w // px + 2))[:h, :w]
+        cur = np.broadcast_to(big, (f, h, w)).copy()
+        ref = np.broadcast_to(big, (f, r, h, w)).copy()
     else:  # a smooth picture + noise, the references shifted copies of it
         yy, xx = np.mgrid[0:h + 256, 0:w + 256]
         base = ((3 * xx + 2 * yy) >> 2) + rng.integers(0, 16, (h + 256, w + 256))
@@ -48,7 +70,7 @@ def main():
         rr = int(rng.choice([1, 3, 7, 16, 33, 64, 100, 128]))
         f, r = int(rng.integers(1, 4)), int(rng.integers(1, 4))
         pad = int(rng.choice([0, 4, 64]))  # row stride = width + pad
-        kind = str(rng.choice(["noise", "flat", "shift", "shift"]))
+        kind = str(rng.choice(["noise", "flat", "shift", "shift", "spots", "lowamp", "mixed", "repeat"]))
         cur, ref = content(rng, kind, f, r, h, w)
         # planes as views of wider buffers: the stride is not the width
         cbuf = torch.zeros((f, h, w + pad), dtype=torch.uint8, device="cuda")

@@ -9,6 +9,8 @@ from x265_amd.pipeline import MeTqPipeline
 x265_amd.init(0)
 lib = x265_amd.api._lib()
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+if len(sys.argv) > 2:   # forced shape of the exact kernel: 8 or 16 waves
+    lib.x265amd_debug_sea_shape(0, int(sys.argv[2]))
 seq = np.stack([synth.pad_plane(f, 64) for f in synth.make_sequence(1920, 1080, nf + 1, search_range=64, seed=12345)])
 pipe = MeTqPipeline(torch.from_numpy(seq).cuda(), ctu=64, search_range=64, nrefs=1, method="sea")
 for _ in range(10):
