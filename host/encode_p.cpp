@@ -43,14 +43,23 @@ struct File {
 struct Batch {  // one batch of segments: its encoder, its stream, its pinned buffers
     void *stream = nullptr;
     std::unique_ptr<GopEncoder> enc;
-    std::unique_ptr<PinnedBuffer> up, lvl, mv, cbf;
-    Batch(int w, int h, int nseg, int range, int qp, bool own_stream)
+    std::unique_ptr<PinnedBuffer> up, lvl, mv, cbf, table, words;
+    bool packed, direct = false;
+    size_t words_down = 0;
+    size_t step_bytes = 0;
+    Batch(int w, int h, int nseg, int range, int qp, bool own_stream, bool packed_, int nframes) : packed(packed_)
     {
         check(x265amd_init(0), "x265amd_init");
         if (own_stream) check(x265amd_stream_create(&stream), "x265amd_stream_create");
         enc.reset(new GopEncoder(w, h, nseg, range, qp, 0, stream));
-        up.reset(new PinnedBuffer(enc->frame_bytes() * nseg));
-        lvl.reset(new PinnedBuffer(2 * enc->frame_bytes() * nseg));
+        step_bytes = enc->frame_bytes() * nseg;
+        up.reset(new PinnedBuffer(step_bytes * nframes));  // every picture of the run waits here
+        if (packed) {
+            table.reset(new PinnedBuffer(4 * enc->packed_table_words()));
+            words.reset(new PinnedBuffer(4 * enc->packed_words_worst()));
+        } else {
+            lvl.reset(new PinnedBuffer(2 * enc->frame_bytes() * nseg));
+        }
         mv.reset(new PinnedBuffer(sizeof(x265amd_mv) * enc->ctus() * nseg));
         cbf.reset(new PinnedBuffer(12 * enc->tus() * nseg));
     }
@@ -59,32 +68,59 @@ struct Batch {  // one batch of segments: its encoder, its stream, its pinned bu
         enc.reset();
         if (stream) x265amd_stream_destroy(stream);
     }
-    void go() { enc->encode_p(up->as()); enc->fetch_async(mv->as<x265amd_mv>(), lvl->as<int16_t>(), nullptr, cbf->as<uint32_t>()); }
+    void go(int t)
+    {
+        enc->encode_p(up->as() + (size_t)t * step_bytes);
+        if (packed)  // the table says which TUs are coded: the sums stay on the device
+            enc->fetch_packed_async(mv->as<x265amd_mv>(), table->as<uint32_t>(), words->as<uint32_t>(), enc->packed_words_worst(), 0, direct);
+        else
+            enc->fetch_async(mv->as<x265amd_mv>(), lvl->as<int16_t>(), nullptr, cbf->as<uint32_t>());
+    }
+    void finish()
+    {
+        enc->sync();
+        if (packed) words_down = enc->fetch_packed_finish();
+    }
 };
 
-// nbatch = 1: upload, kernels, download strictly one after the other.  nbatch = 2: the segments split into
-// two batches on two streams, so that one batch's PCIe copies run under the other's kernels.
-static void bench_one(const std::vector<uint8_t> &file, int w, int h, int nframes, int qp, int range, int nseg, int nbatch)
+// nbatch = 1: upload, kernels, download strictly one after the other.  nbatch = 2, 4: the segments split into
+// batches on streams of their own, so that one batch's PCIe copies run under the others' kernels.
+// (Waiting for a batch only when its next picture is due, so that the batches drift apart, was measured too and
+// gains nothing: DESIGN.md section 5.)
+static void bench_one(const std::vector<uint8_t> &file, int w, int h, int nframes, int qp, int range, int nseg, int nbatch, int mode)
 {
+    const bool packed = mode >= 1;  // mode 2: the kernels write the packed levels into the host's memory themselves
+
     std::vector<std::unique_ptr<Batch>> bs;
-    for (int b = 0; b < nbatch; b++) bs.emplace_back(new Batch(w, h, nseg / nbatch, range, qp, nbatch > 1));
+    const int nsegb = nseg / nbatch;
+    for (int b = 0; b < nbatch; b++) {
+        bs.emplace_back(new Batch(w, h, nsegb, range, qp, nbatch > 1, packed, nframes));
+        bs.back()->direct = mode == 2;
+    }
     const size_t fsz = bs[0]->enc->frame_bytes();
-    auto feed = [&](int t) {
-        for (auto &b : bs)
-            for (int s = 0; s < nseg / nbatch; s++) memcpy(b->up->as() + s * fsz, file.data() + (size_t)t * fsz, fsz);
-    };
-    double best = 1e30, total = 0;
+    for (auto &b : bs)  // a real host would read / receive the frames: they wait in pinned memory, not timed
+        for (int t = 0; t < nframes; t++)
+            for (int s = 0; s < nsegb; s++) memcpy(b->up->as() + ((size_t)t * nsegb + s) * fsz, file.data() + (size_t)t * fsz, fsz);
+    double best = 1e30, total = 0, down_total = 0;
     int pics = 0;
+    bool counted = false;
+    auto finish = [&](Batch &b) {
+        b.finish();
+        if (counted)
+            down_total += packed ? 4.0 * b.words_down + b.table->bytes() + b.mv->bytes() : (double)(b.lvl->bytes() + b.mv->bytes() + b.cbf->bytes());
+    };
+    auto since = [](std::chrono::steady_clock::time_point t0) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     for (int rep = 0; rep < 3; rep++) {  // first repetition = warm-up
-        feed(0);
+        counted = rep > 0;
         for (auto &b : bs) b->enc->set_reference(b->up->as());
         for (auto &b : bs) b->enc->sync();
         for (int t = 1; t < nframes; t++) {
-            feed(t);  // a real host would read / receive the frames here: not timed
             const auto t0 = std::chrono::steady_clock::now();
-            for (auto &b : bs) b->go();
-            for (auto &b : bs) b->enc->sync();
-            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            for (auto &b : bs) b->go(t);
+            for (auto &b : bs) finish(*b);
+            const double ms = since(t0);
             if (rep) {
                 best = ms < best ? ms : best;
                 total += ms;
@@ -93,12 +129,11 @@ static void bench_one(const std::vector<uint8_t> &file, int w, int h, int nframe
         }
     }
     const double mpix = (double)w * h * nseg / 1e6;
-    size_t down = 0;
-    for (auto &b : bs) down += b->lvl->bytes() + b->mv->bytes() + b->cbf->bytes();
-    printf("{\"host\": \"c++\", \"pcie_inclusive\": true, \"width\": %d, \"height\": %d, \"nseg\": %d, \"streams\": %d, "
-           "\"pictures\": %d, \"ms_per_step_mean\": %.4f, \"ms_per_step_best\": %.4f, \"mpixels_per_s_mean\": %.1f, "
-           "\"bytes_up_per_step\": %zu, \"bytes_down_per_step\": %zu}\n",
-           w, h, nseg, nbatch, pics, total / pics, best, mpix / (total / pics) * 1e3, fsz * nseg, down);
+    printf("{\"host\": \"c++\", \"pcie_inclusive\": true, \"levels\": \"%s\", \"width\": %d, \"height\": %d, \"nseg\": %d, "
+           "\"streams\": %d, \"pictures\": %d, \"ms_per_step_mean\": %.4f, \"ms_per_step_best\": %.4f, \"mpixels_per_s_mean\": %.1f, "
+           "\"bytes_up_per_step\": %zu, \"bytes_down_per_step\": %.0f}\n",
+           mode == 2 ? "packed_direct" : packed ? "packed" : "dense", w, h, nseg, nbatch, pics, total / pics, best,
+           mpix / (total / pics) * 1e3, fsz * nseg, down_total / pics);
 }
 
 static int bench(char **a)
@@ -111,8 +146,11 @@ static int bench(char **a)
         File in(a[0], "rb");
         if (fread(file.data(), 1, file.size(), in.f) != file.size()) throw std::runtime_error("short read");
     }
-    bench_one(file, w, h, nframes, qp, range, nseg, 1);
-    if (nseg % 2 == 0) bench_one(file, w, h, nframes, qp, range, nseg, 2);
+    for (int mode = 0; mode < 3; mode++) {  // the levels as dense planes, then as x265amd_pack_levels leaves them (copied / written direct)
+        bench_one(file, w, h, nframes, qp, range, nseg, 1, mode);
+        for (int nb = 2; nb <= 4; nb *= 2)
+            if (nseg % nb == 0 && nseg >= 2 * nb - 2) bench_one(file, w, h, nframes, qp, range, nseg, nb, mode);
+    }
     return 0;
 }
 
@@ -139,7 +177,10 @@ int main(int argc, char **argv)
         std::vector<uint8_t> frame(fsz), rec(fsz);
         std::vector<int16_t> level(fsz);
         std::vector<x265amd_mv> mv(enc.ctus());
-        std::vector<uint32_t> cbf(3 * enc.tus());
+        std::vector<uint32_t> cbf(3 * enc.tus()), ptable(enc.packed_table_words()), pwords(enc.packed_words_worst());
+        std::vector<int16_t> plane((size_t)w * h);
+        size_t packed_words = 0;
+        PinnedBuffer dtable(4 * ptable.size()), dwords(4 * pwords.size()), dmv(sizeof(x265amd_mv) * mv.size());
         File in(argv[1], "rb"), fmv(prefix + ".mv", "wb"), flvl(prefix + ".lvl", "wb"), frec(prefix + ".rec", "wb");
         for (int t = 0; t < nframes; t++) {
             if (fread(frame.data(), 1, fsz, in.f) != fsz) throw std::runtime_error("short read at frame " + std::to_string(t));
@@ -161,14 +202,35 @@ int main(int argc, char **argv)
             }
             enc.encode_p(frame.data());
             enc.fetch(mv.data(), level.data(), rec.data(), cbf.data());
+            {  // the packed form of the same levels must say the same thing
+                const size_t words = enc.fetch_packed(nullptr, ptable.data(), pwords.data(), pwords.size());
+                if (words > pwords.size()) throw std::runtime_error("packed levels: more words than levels");
+                const size_t ysz = (size_t)w * h, offs[3] = {0, ysz, ysz + ysz / 4};
+                for (int pl = 0; pl < 3; pl++) {
+                    enc.unpack_plane(ptable.data(), pwords.data(), pl, 0, plane.data());
+                    if (memcmp(plane.data(), level.data() + offs[pl], 2 * (pl ? ysz / 4 : ysz)))
+                        throw std::runtime_error("packed levels differ from the dense plane " + std::to_string(pl));
+                }
+                packed_words = words;
+                // and so must what the kernels write into page-locked memory themselves
+                enc.fetch_packed_async(dmv.as<x265amd_mv>(), dtable.as<uint32_t>(), dwords.as<uint32_t>(), pwords.size(), 0, true);
+                enc.sync();
+                if (enc.fetch_packed_finish() != words) throw std::runtime_error("packed levels, direct: another number of words");
+                for (int pl = 0; pl < 3; pl++) {
+                    enc.unpack_plane(dtable.as<uint32_t>(), dwords.as<uint32_t>(), pl, 0, plane.data());
+                    if (memcmp(plane.data(), level.data() + offs[pl], 2 * (pl ? ysz / 4 : ysz)))
+                        throw std::runtime_error("packed levels, direct, differ from the dense plane " + std::to_string(pl));
+                }
+                if (memcmp(dmv.as(), mv.data(), sizeof(x265amd_mv) * mv.size())) throw std::runtime_error("vectors, direct, differ");
+            }
             fwrite(mv.data(), sizeof(x265amd_mv), mv.size(), fmv.f);
             fwrite(level.data(), 2, level.size(), flvl.f);
             fwrite(rec.data(), 1, rec.size(), frec.f);
             uint64_t sad = 0, coded = 0;
             for (const x265amd_mv &m : mv) sad += m.sad;
             for (uint32_t c : cbf) coded += c != 0;
-            printf("POC %d: %zu CTUs, sum of best SADs %llu, coded TUs %llu of %zu, recon fnv1a %016llx%s\n", enc.poc(), mv.size(),
-                   (unsigned long long)sad, (unsigned long long)coded, cbf.size(), (unsigned long long)fnv1a(rec.data(), fsz),
+            printf("POC %d: %zu CTUs, sum of best SADs %llu, coded TUs %llu of %zu, packed levels %zu words, recon fnv1a %016llx%s\n", enc.poc(), mv.size(),
+                   (unsigned long long)sad, (unsigned long long)coded, cbf.size(), packed_words, (unsigned long long)fnv1a(rec.data(), fsz),
                    enc.exhaustive_fallback() ? " (every-candidate search)" : "");
         }
     } catch (const std::exception &e) {

@@ -90,6 +90,11 @@ int x265amd_malloc_host(void **h_ptr, size_t bytes);
 int x265amd_free_host(void *h_ptr);
 int x265amd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int x265amd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
+/* Device memory into page-locked host memory (x265amd_malloc_host's; anything else is X265AMD_ERR_ARG) by a kernel
+ * of `stream` that stores across the link, instead of by the copy engine: for the small things that come down
+ * after the kernels of a picture (vectors, counts), where a copy-engine transfer costs more in set-up than in
+ * bytes.  bytes and both pointers multiples of 4.  The reference has no device boundary and nothing like it. */
+int x265amd_copy_to_host(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int x265amd_stream_sync(void *stream);
 /* a hipStream_t for hosts without HIP headers: two batches of segments on two streams overlap one batch's
  * PCIe copies with the other's kernels (host/encode_p.cpp --bench) */
@@ -387,6 +392,31 @@ int x265amd_quant_plane(const int16_t *d_coef, int16_t *d_level, int stride, int
                         int tu, int qp, int slice_type, uint32_t *d_abs_sum, void *stream);
 int x265amd_dequant_plane(const int16_t *d_level, int16_t *d_coef, int stride, int width,
                           int height, int tu, int qp, void *stream);
+
+/* ------------------------------------------------ levels for the trip to the host */
+
+/* Compaction of a plane (or a batch of planes) of quantised levels: what the host's entropy coder walks per transform
+ * unit is its coded-block flag and its NON-ZERO levels (xEncodeCoeffNxN, src/encode.cpp:270-461; bCbf from xQuant's
+ * sum, :888-890), and the dense Int16 planes are what bounds a host loop over PCIe.  The reference has no such
+ * interface (no device boundary: it reads psCoef in place, inc/x265.h:125-131).
+ *
+ *   d_tu_table [nframes][ntu][2]  per TU (raster order of the plane): index of its first word in d_words, number of words
+ *   d_words                       word = (position in the TU's raster, y * tu + x) << 16 | (level & 0xffff); a TU's words
+ *                                 are contiguous and in raster order; TUs take their room from *d_cursor in the order they
+ *                                 finish (the table says where), so several calls -- Y, U, V -- may share cursor and words
+ *   d_cursor                      words asked for so far; x265amd_pack_levels_begin zeroes it.  It keeps counting past
+ *                                 `capacity`: words at or beyond it are not written (a TU whose entry ends beyond it is
+ *                                 incomplete), and cursor > capacity tells the host to take the dense plane instead
+ *   d_abs_sum                     optional: xQuant's per-TU sums as the transform entry points leave them; a TU whose sum
+ *                                 is 0 is entered as empty without being read
+ * d_tu_table and d_words may be page-locked host memory (x265amd_malloc_host): the words then cross the link as
+ * they are written and there is nothing to copy afterwards (d_cursor stays in device memory: it is an atomic).
+ * Any stride works; planes whose rows start on 16-byte boundaries (d_level, 2 * stride, 2 * frame_stride multiples
+ * of 16) take the fast path with one 16-byte load per lane. */
+int x265amd_pack_levels_begin(uint32_t *d_cursor, void *stream);
+int x265amd_pack_levels(const int16_t *d_level, int width, int height, int stride, int tu, int nframes,
+                        int64_t frame_stride, const uint32_t *d_abs_sum, int64_t abs_sum_frame_stride,
+                        uint32_t *d_tu_table, uint32_t *d_words, uint32_t capacity, uint32_t *d_cursor, void *stream);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,7 @@ def test_cpp_host_closed_loop_vs_oracle(gpu, oracle, tmp_path):
                        timeout=120)
     assert r.returncode == 0, r.stderr
     assert r.stdout.count("POC") == T - 1 and "every-candidate" not in r.stdout
+    assert r.stdout.count("packed levels") == T - 1  # each picture's packed levels unpacked and compared with the dense ones
     nctu = (W // 64) * (H // 64)
     gmv = np.fromfile(prefix + ".mv", MV_DTYPE).reshape(T - 1, nctu)
     glvl = np.fromfile(prefix + ".lvl", np.int16).reshape(T - 1, fsz)
@@ -88,7 +89,8 @@ def test_cpp_host_bench_mode_streams_and_pinned_memory(gpu, tmp_path):
                        timeout=120)
     assert r.returncode == 0, r.stderr
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert [l["streams"] for l in lines] == [1, 2]
+    assert [(l["levels"], l["streams"]) for l in lines] == [(lv, st) for lv in ("dense", "packed", "packed_direct") for st in (1, 2)]
+    assert lines[2]["bytes_down_per_step"] < lines[0]["bytes_down_per_step"]
     for l in lines:
         assert l["pcie_inclusive"] and l["nseg"] == 2 and l["mpixels_per_s_mean"] > 0
         assert l["bytes_up_per_step"] == 2 * W * H * 3 // 2

@@ -6,8 +6,8 @@ take torch CUDA tensors (torch = device memory + streams only), the synthetic
 sequence generator, and the frame-sharding helper for multi-GPU runs.
 """
 from .api import (LIB_PATH, MAX_SAD, MODE_INVALID, MV_DTYPE, SLICE_B, SLICE_I, SLICE_P, X265AmdError,  # noqa: F401
-                  chroma_qp, dequant_plane, idct_add, init, intra_decide_luma, intra_encode_frame, intra_encode_frames, intra_write_picture, load_library, me_fullsearch, me_fullsearch_pu, me_fullsearch_pu_all, PU_SHAPES, me_static_workspace_bytes, me_workspace_bytes, mv_to_numpy, quant_plane,
-                  sad_blocks, satd_blocks, tq_forward, tq_inverse, tq_roundtrip)
+                  chroma_qp, dequant_plane, idct_add, init, intra_decide_luma, intra_encode_frame, intra_encode_frames, intra_write_picture, load_library, me_fullsearch, me_fullsearch_pu, me_fullsearch_pu_all, PU_SHAPES, me_static_workspace_bytes, me_workspace_bytes, mv_to_numpy, pack_levels, quant_plane,
+                  sad_blocks, satd_blocks, tq_forward, tq_inverse, tq_roundtrip, unpack_levels)
 
 from . import dropin  # noqa: F401,E402
 from .pipeline import ClosedLoopGop, MeTqPipeline  # noqa: F401,E402

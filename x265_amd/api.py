@@ -62,6 +62,10 @@ SIGNATURES = {
     "x265amd_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "x265amd_stream_destroy": (C.c_int, [C.c_void_p]),
     "x265amd_chroma_qp": (C.c_int, [C.c_int]),
+    "x265amd_copy_to_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "x265amd_pack_levels_begin": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "x265amd_pack_levels": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p,
+                                       C.c_int64, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "x265amd_sad_blocks": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "x265amd_satd_blocks": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
@@ -225,6 +229,54 @@ def satd_blocks(w, n, src, stride_src, ref, stride_ref, src_off, ref_off):
     _check(_lib().x265amd_satd_blocks(w, n, src.data_ptr(), stride_src, ref.data_ptr(), stride_ref,
                                       src_off.data_ptr(), ref_off.data_ptr(), nb, out.data_ptr(), _stream()),
            "x265amd_satd_blocks")
+    return out
+
+
+def pack_levels(level, tu, abs_sum=None, capacity=None, out=None, begin=True):
+    """x265amd_pack_levels on a level plane [H][W] or batch [F][H][W] (int16, on the GPU): per TU where its non-zero
+    levels are and how many, and the levels as (position << 16 | level) words.  Returns (table int32 [F][ntu][2],
+    words int32 [capacity], cursor int32 [1]); `out` = those three to reuse, `begin=False` to go on filling them."""
+    lp, f, h, w, stride, fs = _planes(level, torch.int16, "level")
+    ntu = (h // tu) * (w // tu) if tu > 0 else 0
+    if out is None:
+        cap = f * h * w if capacity is None else int(capacity)
+        out = (torch.empty((f, ntu, 2), dtype=torch.int32, device=level.device),
+               torch.empty(max(cap, 1), dtype=torch.int32, device=level.device),
+               torch.zeros(1, dtype=torch.int32, device=level.device))
+    table, words, cursor = out
+    cap = words.numel() if capacity is None else int(capacity)
+    if table.numel() < f * ntu * 2 or cap > words.numel():
+        raise ValueError("pack_levels: table / words too small")
+    sp, sfs = 0, 0
+    if abs_sum is not None:
+        _dev(abs_sum, torch.int32, "abs_sum")
+        if not abs_sum.is_contiguous() or abs_sum.numel() < f * ntu:
+            raise ValueError("abs_sum: need a contiguous int32 tensor of [F][ntu]")
+        sp, sfs = abs_sum.data_ptr(), ntu
+    if begin:
+        _check(_lib().x265amd_pack_levels_begin(cursor.data_ptr(), _stream()), "x265amd_pack_levels_begin")
+    _check(_lib().x265amd_pack_levels(lp, w, h, stride, tu, f, fs, sp, sfs, table.data_ptr(), words.data_ptr(), cap,
+                                      cursor.data_ptr(), _stream()), "x265amd_pack_levels")
+    return table, words, cursor
+
+
+def unpack_levels(table, words, width, height, tu):
+    """The dense planes back from pack_levels' output (host side, numpy): table [F][ntu][2], words [n]."""
+    table = np.asarray(table).astype(np.int64)
+    words = np.ascontiguousarray(words)
+    words = words.view(np.uint32) if words.dtype == np.int32 else words.astype(np.uint32)
+    f, ntu = table.shape[0], table.shape[1]
+    tus_x = width // tu
+    out = np.zeros((f, height, width), np.int16)
+    for fi in range(f):
+        for t in range(ntu):
+            off, cnt = table[fi, t]
+            if cnt == 0:
+                continue
+            wd = words[off:off + cnt]
+            pos = (wd >> 16).astype(np.int64)
+            ty, tx = divmod(t, tus_x)
+            out[fi, ty * tu + pos // tu, tx * tu + pos % tu] = (wd & 0xffff).astype(np.uint16).view(np.int16)
     return out
 
 

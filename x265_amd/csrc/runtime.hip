@@ -1,5 +1,6 @@
 // runtime.hip -- device selection, error strings, memory helpers of the C-ABI
 #include <string.h>
+#include <algorithm>
 
 #include "common.h"
 
@@ -131,6 +132,34 @@ extern "C" int x265amd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, 
 {
     X265AMD_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return X265AMD_OK;
+}
+// x265amd_copy_to_host: the copy as a kernel of the stream.  T = uint4 when everything is 16-byte aligned.
+template <class T>
+__global__ __launch_bounds__(256) void copy_to_host_kernel(T *__restrict__ dst, const T *__restrict__ src, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+extern "C" int x265amd_copy_to_host(void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    if (!initialised()) return X265AMD_ERR_NOT_INIT;
+    if (!h_dst || !d_src || (bytes & 3) || ((uintptr_t)h_dst & 3) || ((uintptr_t)d_src & 3)) return X265AMD_ERR_ARG;
+    if (bytes == 0) return X265AMD_OK;
+    void *mapped = nullptr;  // fails for memory that is not page-locked and mapped (x265amd_malloc_host's is)
+    if (hipHostGetDevicePointer(&mapped, h_dst, 0) != hipSuccess || !mapped) {
+        (void)hipGetLastError();
+        return X265AMD_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (((bytes | (uintptr_t)mapped | (uintptr_t)d_src) & 15) == 0) {
+        const size_t n = bytes / 16;
+        const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+        hipLaunchKernelGGL(copy_to_host_kernel<uint4>, dim3(grid), dim3(256), 0, st, (uint4 *)mapped, (const uint4 *)d_src, n);
+    } else {
+        const size_t n = bytes / 4;
+        const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 1024);
+        hipLaunchKernelGGL(copy_to_host_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, (uint32_t *)mapped, (const uint32_t *)d_src, n);
+    }
+    return hip_status(hipGetLastError());
 }
 extern "C" int x265amd_stream_sync(void *stream)
 {
