@@ -463,7 +463,10 @@ def closed_loop(args, grp, nw, nh, rng, nseg, qp):
     yuv = torch.from_numpy(np.stack(segs)).cuda()          # [S][T][W*H*3/2]
     enc = ClosedLoopGop(w, h, nseg, search_range=rng, qp=qp)
     enc.set_reference(yuv[:, 0].contiguous())
-    pics = [yuv[:, t].contiguous() for t in range(1, T)]
+    # the pictures go back and forth, 1 .. T-1, T-2 .. 0, 1 ..: every step codes a picture next in time to its reference,
+    # as in a real segment (1 .. T-1 over and over made every (T-1)-th step a scene cut, T-1 pictures back, and the
+    # reconstructions after it noisier: tools/gop_steps.py)
+    pics = [yuv[:, t].contiguous() for t in list(range(1, T)) + list(range(T - 2, -1, -1))]
     k = [0]
 
     def step(_k=None):
@@ -479,7 +482,7 @@ def closed_loop(args, grp, nw, nh, rng, nseg, qp):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{nw}x{nh} 4:2:0 (padded {w}x{h}), closed loop: {nseg} GOP segments per GPU advance one P "
                                    f"picture per step; +-{rng} search on the previous reconstruction, luma 32x32 and chroma "
-                                   f"16x16 TQ + reconstruction QP{qp}, reference rotation", "name": args.workload,
+                                   f"16x16 TQ + reconstruction QP{qp}, reference rotation; pictures in time order back and forth", "name": args.workload,
                        "me_method": enc.method},
         }), flush=True)
     grp.close()

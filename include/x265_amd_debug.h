@@ -47,6 +47,11 @@ void x265amd_debug_intra_fused(int on);
  * few CUs), 512 (8 waves, two to a compute unit) or 256 (4 waves, four to a compute unit): a batch's steps; 0 (default)
  * = by the number of CUs in the step */
 void x265amd_debug_intra_threads(int threads);
+/* d_stats != NULL: the fused intra kernel (CU 32) leaves 16 u32 per (frame of the batch, CU): shader-clock stamps [0] start,
+ * [1] source and reference samples in LDS, [2] smoothing / DC / most probable modes, [3] the 35 luma and 5 chroma SADs, [4] luma
+ * argmin, [5] luma prediction stored (and the chroma SAD of the luma mode), [6] chroma argmin, [7] chroma predictions stored,
+ * [8] the barrier before the transform stage, [9] its luma wave done.  NULL switches back.  tools/intra_stats.py reads them. */
+void x265amd_debug_set_intra_stats(uint32_t *d_stats);
 
 /* Where and when the waves of the matrix-core TQ kernel ran: with a non-null device buffer of nwaves x 4
  * 64-bit words (nwaves >= 4 x the workgroups of the launch, else nothing is recorded; zeroed by the caller) every wave of the following

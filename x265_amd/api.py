@@ -120,6 +120,7 @@ DEBUG_SIGNATURES = {
     "x265amd_debug_tq_path": (None, [C.c_int]),
     "x265amd_debug_intra_fused": (None, [C.c_int]),
     "x265amd_debug_intra_threads": (None, [C.c_int]),
+    "x265amd_debug_set_intra_stats": (None, [C.c_void_p]),
     "x265amd_debug_tq_trace": (None, [C.c_void_p, C.c_int]),
     "x265amd_debug_tq_units_per_wg": (None, [C.c_int]),
     "x265amd_debug_me_fullsearch_basic": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -45,6 +45,7 @@ struct DebugState {
     int tq_trace_waves = 0;
     int tq_units_per_wg = 0;              // x265amd_debug_tq_units_per_wg
     int intra_fused = 1;                  // x265amd_debug_intra_fused
+    uint32_t *intra_stats = nullptr;      // x265amd_debug_set_intra_stats
     int intra_threads = 0;                // x265amd_debug_intra_threads
 };
 

@@ -18,16 +18,65 @@
 
 namespace x265amd {
 
-// src/table.cpp:32-39, 49-56, 59-66
-__device__ const uint8_t kIntraFilter[4][35] = {
+// src/table.cpp:32-39, 49-56, 59-66.  The tables as they stand there, and what the kernels use instead: the same values
+// out of packed constants by shifts (a mode is wave-uniform nearly everywhere, so this is scalar arithmetic; indexing
+// a table in memory cost a vector load per task of the SAD phase, waited for before anything else could start).
+constexpr uint8_t kIntraFilterTab[4][35] = {
     {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
     {1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1},
     {1, 0, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1},
     {1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1, 1}};
-__device__ const int8_t kIntraAngle[35] = {0,   0,   32,  26,  21,  17,  13,  9,  5,  2,  0,  -2, -5, -9, -13, -17, -21, -26,
-                                           -32, -26, -21, -17, -13, -9,  -5,  -2, 0,  2,  5,  9,  13, 17, 21,  26,  32};
-__device__ const int16_t kIntraInvAngle[35] = {0,   0,   256, 315, 390, 482, 630, 910, 1638, 4096, 0,   4096, 1638, 910, 630, 482, 390, 315,
-                                               256, 315, 390, 482, 630, 910, 1638, 4096, 0,  4096, 1638, 910, 630, 482, 390, 315, 256};
+constexpr int8_t kIntraAngleTab[35] = {0,   0,   32,  26,  21,  17,  13,  9,  5,  2,  0,  -2, -5, -9, -13, -17, -21, -26,
+                                       -32, -26, -21, -17, -13, -9,  -5,  -2, 0,  2,  5,  9,  13, 17, 21,  26,  32};
+constexpr int16_t kIntraInvAngleTab[35] = {0,   0,   256, 315, 390, 482, 630, 910, 1638, 4096, 0,   4096, 1638, 910, 630, 482, 390, 315,
+                                           256, 315, 390, 482, 630, 910, 1638, 4096, 0,  4096, 1638, 910, 630, 482, 390, 315, 256};
+
+// |angle| by distance from the pure horizontal / vertical mode, 6 bits each; the inverse angles of distances 1..4 and 5..8,
+// 13 bits each; the filter flags of a block size as one bit per mode
+constexpr uint64_t kAbsAngles = 0ull | (2ull << 6) | (5ull << 12) | (9ull << 18) | (13ull << 24) | (17ull << 30) | (21ull << 36) | (26ull << 42) | (32ull << 48);
+constexpr uint64_t kInvLo = 4096ull | (1638ull << 13) | (910ull << 26) | (630ull << 39);
+constexpr uint64_t kInvHi = 482ull | (390ull << 13) | (315ull << 26) | (256ull << 39);
+constexpr uint64_t intra_filter_mask(int size_idx)
+{
+    uint64_t m = 0;
+    for (int i = 0; i < 35; i++) m |= (uint64_t)kIntraFilterTab[size_idx][i] << i;
+    return m;
+}
+constexpr uint64_t kFilterMask[4] = {intra_filter_mask(0), intra_filter_mask(1), intra_filter_mask(2), intra_filter_mask(3)};
+
+__host__ __device__ constexpr int intra_angle(int mode)
+{
+    if (mode < 2) return 0;
+    const int d = mode < 18 ? mode - 10 : mode - 26;
+    const int ad = d < 0 ? -d : d;
+    const int a = (int)((kAbsAngles >> (6 * ad)) & 63u);
+    return ((d < 0) == (mode < 18)) ? a : -a;
+}
+__host__ __device__ constexpr int intra_inv_angle(int mode)
+{
+    if (mode < 2) return 0;
+    const int d = mode < 18 ? mode - 10 : mode - 26;
+    const int ad = d < 0 ? -d : d;
+    if (ad == 0) return 0;
+    return (int)(((ad <= 4 ? kInvLo >> (13 * (ad - 1)) : kInvHi >> (13 * (ad - 5)))) & 8191u);
+}
+// size_idx = log2(N) - 2
+template <int SIZE_IDX> __host__ __device__ constexpr int intra_filter(int mode)
+{
+    constexpr uint64_t m = kFilterMask[SIZE_IDX];
+    return (int)((m >> mode) & 1u);
+}
+constexpr bool intra_tables_agree()
+{
+    for (int m = 0; m < 35; m++) {
+        if (intra_angle(m) != kIntraAngleTab[m] || intra_inv_angle(m) != kIntraInvAngleTab[m]) return false;
+        if (intra_filter<0>(m) != kIntraFilterTab[0][m] || intra_filter<1>(m) != kIntraFilterTab[1][m] ||
+            intra_filter<2>(m) != kIntraFilterTab[2][m] || intra_filter<3>(m) != kIntraFilterTab[3][m])
+            return false;
+    }
+    return true;
+}
+static_assert(intra_tables_agree(), "packed intra tables differ from src/table.cpp");
 
 // |a - b| + acc in one instruction (v_sad_u32)
 __device__ __forceinline__ uint32_t sad_acc(uint32_t a, uint32_t b, uint32_t acc)
@@ -37,8 +86,35 @@ __device__ __forceinline__ uint32_t sad_acc(uint32_t a, uint32_t b, uint32_t acc
     return d;
 }
 
+// Sum / minimum over the 64 lanes of a wave, the same value in every lane's scalar copy: four DPP steps inside the rows of
+// 16 lanes (pairs, quads, half rows, rows), then the four row results through v_readlane.  All 64 lanes must be active.
+// (__shfl_xor goes through the LDS crossbar: six dependent trips of it per reduction were a fifth of the SAD phase.)
+template <int CTRL> __device__ __forceinline__ uint32_t intra_dpp(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t s)
+{
+    s += intra_dpp<0xb1>(s);   // quad_perm [1,0,3,2]
+    s += intra_dpp<0x4e>(s);   // quad_perm [2,3,0,1]
+    s += intra_dpp<0x141>(s);  // row_half_mirror
+    s += intra_dpp<0x140>(s);  // row_mirror
+    return (uint32_t)__builtin_amdgcn_readlane((int)s, 0) + (uint32_t)__builtin_amdgcn_readlane((int)s, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)s, 32) + (uint32_t)__builtin_amdgcn_readlane((int)s, 48);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t s)
+{
+    s = min(s, intra_dpp<0xb1>(s));
+    s = min(s, intra_dpp<0x4e>(s));
+    s = min(s, intra_dpp<0x141>(s));
+    s = min(s, intra_dpp<0x140>(s));
+    return min(min((uint32_t)__builtin_amdgcn_readlane((int)s, 0), (uint32_t)__builtin_amdgcn_readlane((int)s, 16)),
+               min((uint32_t)__builtin_amdgcn_readlane((int)s, 32), (uint32_t)__builtin_amdgcn_readlane((int)s, 48)));
+}
+
 constexpr int kMaxRef = 4 * 32 + 1;
-constexpr int kMainRow = 3 * 32 + 8;  // refMain of a mode: samples -N .. 2N, and one past the end that a zero weight may touch
+constexpr int kMainRow = 3 * 32 + 8;
+constexpr int kRefRow = kMaxRef + 7;  // a sample array in the frame kernels' LDS: 4-byte multiples, room for the last quad's window  // refMain of a mode: samples -N .. 2N, and one past the end that a zero weight may touch
 
 // pixel (r, c) of mode `mode`; ref = the sample array the mode reads (smoothed or not), dc = the DC value.
 // LUMA: the edge smoothing of DC and of the pure horizontal / vertical modes (bLuma of the reference's functions)
@@ -61,7 +137,7 @@ template <int N, bool LUMA = true> __device__ __forceinline__ int intra_pixel(co
     // angular (src/encode.cpp:1446-1534): the main side is the left column for modes 2..17 (built as a row and
     // transposed at the end: swap the roles of r and c instead), the row above for 18..34
     const bool hor = mode < 18;
-    const int ang = kIntraAngle[mode], inv = kIntraInvAngle[mode];
+    const int ang = intra_angle(mode), inv = intra_inv_angle(mode);
     const int k = hor ? c : r, x = hor ? r : c;
     const int sgn = hor ? -1 : 1;  // main side: tl[sgn * i]; the other side, projected onto it: tl[-sgn * offset]
     auto main_ref = [&](int i) -> int {
@@ -88,7 +164,7 @@ template <int N> __device__ __forceinline__ void intra_fill_main(const uint8_t *
 {
     const uint8_t *tl = ref + 2 * N;
     const bool hor = mode < 18;
-    const int ang = kIntraAngle[mode], inv = kIntraInvAngle[mode];
+    const int ang = intra_angle(mode), inv = intra_inv_angle(mode);
     const int sgn = hor ? -1 : 1;
     const int lo = ang < 0 ? ((N * ang) >> 5) + 1 : 0;
     for (int i = lane - N; i <= 2 * N; i += 64) {
@@ -103,11 +179,33 @@ template <int N> __device__ __forceinline__ void intra_fill_main(const uint8_t *
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// The same row for the frame kernels, which keep every sample array a second time in reverse (rev[j] = ref[4 N - j]):
+// R = the array in the order the mode walks it -- ref for the modes from 18 on, rev below 18 -- so that, with T = R + 2 N,
+// sample i of the main side is T[i] and the other side projected onto it is T[-offset], whatever the direction.  A mode
+// with a positive angle reads no projected sample: its row IS the array (returned as it lies, nothing is copied).  A
+// negative angle reads entries lo .. N only, at most 2 N of them: one store per lane, no loop.  Returns the row
+// (row[N + i] = sample i), 4-byte aligned like R and `row`.
+template <int N> __device__ __forceinline__ const uint8_t *intra_main_row(const uint8_t *R, int mode, int lane, uint8_t *row)
+{
+    const int ang = intra_angle(mode);
+    if (ang >= 0) return R + N;  // wave-uniform
+    const int inv = intra_inv_angle(mode);
+    const int lo = ((N * ang) >> 5) + 1;
+    const int i = max(lane - (N - 1), lo);  // lanes below lo write entry lo once more (the same value)
+    if (lane < 2 * N) {
+        const int idx = i >= 0 ? i : -(int)((128u + __umul24((unsigned)(-i), (unsigned)inv)) >> 8);
+        row[N + i] = R[2 * N + idx];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return row;
+}
 // pixel (r, c) of angular mode `mode` from its main row (see intra_pixel for the construction)
 template <int N, bool LUMA> __device__ __forceinline__ int intra_ang_pixel(const uint8_t *ref, const uint8_t *row, int mode, int r, int c)
 {
     const bool hor = mode < 18;
-    const int ang = kIntraAngle[mode];
+    const int ang = intra_angle(mode);
     const int k = hor ? c : r, x = hor ? r : c;
     const int pos = (k + 1) * ang;
     const int idx = pos >> 5, fact = pos & 31;
@@ -151,7 +249,7 @@ template <int N> __device__ __forceinline__ void intra_dc_value(const uint8_t *r
 {
     int s = 0;
     for (int i = lane; i < 2 * N; i += 64) s += i < N ? ref[2 * N + 1 + i] : ref[2 * N - 1 - (i - N)];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    s = (int)wave_sum_u32((uint32_t)s);
     if (lane == 0) *out = (s + N) / (2 * N);
 }
 
@@ -163,7 +261,7 @@ __device__ __forceinline__ void intra_luma_sads(const uint8_t (*s_ref)[kMaxRef +
 {
     constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
     for (int mode = wave; mode < 35; mode += NWAVES) {
-        const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][mode]];
+        const uint8_t *ref = s_ref[intra_filter<L2 - 2>(mode)];
         uint32_t s = 0;
         if (mode >= 2) {  // wave-uniform
             intra_fill_main<N>(ref, mode, lane, main_row);
@@ -179,7 +277,7 @@ __device__ __forceinline__ void intra_luma_sads(const uint8_t (*s_ref)[kMaxRef +
                 if (i < N * N) s = sad_acc((uint32_t)sp[t], (uint32_t)intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc), s);
             }
         }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        s = wave_sum_u32(s);
         if (lane == 0) s_sad[mode] = s;
     }
 }
@@ -188,42 +286,40 @@ __device__ __forceinline__ void intra_luma_sads(const uint8_t (*s_ref)[kMaxRef +
 // quad q = lane + 64 t read along rows (line k = q / (N / 4), x0 = 4 (q % (N / 4)): row k, columns x0 ..), srch[t] = the
 // same quad of the TRANSPOSED source (column k, rows x0 ..) -- a mode below 18 is the mirrored construction, so it is
 // compared against the transposed block.  Planar and DC take the pixel path.
-template <int N, int PER, int NWAVES>
-__device__ __forceinline__ void intra_luma_sads_quads(const uint8_t (*s_ref)[kMaxRef + 3], const int (&sp)[PER], const uint32_t (&srcv)[PER / 4],
-                                                      const uint32_t (&srch)[PER / 4], int dc, int wave, int lane, uint32_t *s_sad,
-                                                      uint8_t *main_row)
+template <int N, int PER>
+__device__ __forceinline__ uint32_t intra_luma_sad_quads(const uint8_t (*s_ref)[kRefRow], const uint8_t (*s_rev)[kRefRow], const int (&sp)[PER],
+                                                         const uint32_t (&srcv)[PER / 4], const uint32_t (&srch)[PER / 4], int dc, int mode,
+                                                         int lane, uint8_t *row_buf)
 {
     constexpr int L2 = N == 16 ? 4 : 5;
     constexpr int QL = N / 4;  // quads per line
-    for (int mode = wave; mode < 35; mode += NWAVES) {
-        const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][mode]];
-        uint32_t s = 0;
-        if (mode >= 2) {  // wave-uniform
-            intra_fill_main<N>(ref, mode, lane, main_row);
-            const int ang = kIntraAngle[mode];
-            const bool hor = mode < 18;
+    const int filt = intra_filter<L2 - 2>(mode);
+    const uint8_t *ref = s_ref[filt];
+    uint32_t s = 0;
+    if (mode >= 2) {  // wave-uniform
+        const int ang = intra_angle(mode);
+        const bool hor = mode < 18;
+        const uint8_t *main_row = intra_main_row<N>(hor ? s_rev[filt] : ref, mode, lane, row_buf);
 #pragma unroll
-            for (int t = 0; t < PER / 4; t++) {
-                const int q = lane + 64 * t, k = q / QL, x0 = 4 * (q % QL);
-                const int pos = (k + 1) * ang;
-                uint32_t pq = intra_ang_quad(main_row, N + x0 + (pos >> 5) + 1, pos & 31);
-                if (ang == 0 && x0 == 0) {  // modes 10 and 26: the first pixel of a line follows the other side's gradient
-                    const uint8_t *tl = ref + 2 * N;
-                    const int p = (int)(pq & 0xffu) + ((tl[(hor ? 1 : -1) * (k + 1)] - tl[0]) >> 1);
-                    pq = (pq & 0xffffff00u) | (uint32_t)min(max(p, 0), 255);
-                }
-                s = __builtin_amdgcn_sad_u8(pq, hor ? srch[t] : srcv[t], s);
+        for (int t = 0; t < PER / 4; t++) {
+            const int q = lane + 64 * t, k = q / QL, x0 = 4 * (q % QL);
+            const int pos = (k + 1) * ang;
+            uint32_t pq = intra_ang_quad(main_row, N + x0 + (pos >> 5) + 1, pos & 31);
+            if (ang == 0 && x0 == 0) {  // modes 10 and 26: the first pixel of a line follows the other side's gradient
+                const uint8_t *tl = ref + 2 * N;
+                const int p = (int)(pq & 0xffu) + ((tl[(hor ? 1 : -1) * (k + 1)] - tl[0]) >> 1);
+                pq = (pq & 0xffffff00u) | (uint32_t)min(max(p, 0), 255);
             }
-        } else {
-#pragma unroll
-            for (int t = 0; t < PER; t++) {
-                const int i = lane + 64 * t;
-                s = sad_acc((uint32_t)sp[t], (uint32_t)intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc), s);
-            }
+            s = __builtin_amdgcn_sad_u8(pq, hor ? srch[t] : srcv[t], s);
         }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) s_sad[mode] = s;
+    } else {
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+            const int i = lane + 64 * t;
+            s = sad_acc((uint32_t)sp[t], (uint32_t)intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc), s);
+        }
     }
+    return wave_sum_u32(s);
 }
 
 // cost and argmin exactly as src/encode.cpp:725-765: first strict minimum in mode order from MAX_SAD (one thread)
@@ -238,6 +334,20 @@ __device__ __forceinline__ x265amd_intra_best intra_luma_argmin(const uint32_t *
         }
     }
     return x265amd_intra_best{bm, bc};
+}
+
+// The same by a whole wave (all 64 lanes active): lane m < 35 holds mode m's cost, the minimum of (cost << 6 | mode) is
+// the first strict minimum in mode order; every lane gets the answer.  cost < 2^26 (SAD <= 2^18, lambda <= 2^20).
+__device__ __forceinline__ x265amd_intra_best intra_luma_argmin_wave(const uint32_t *s_sad, int m0, int m1, int m2, uint32_t lambda, int lane)
+{
+    uint32_t key = 0xffffffffu;
+    if (lane < 35) {
+        const uint32_t cost = s_sad[lane] + lambda * (lane == m0 ? 1u : (lane == m1 || lane == m2) ? 2u : 3u);
+        if (cost < X265AMD_MAX_SAD) key = (cost << 6) | (uint32_t)lane;
+    }
+    key = wave_min_u32(key);
+    if (key == 0xffffffffu) return x265amd_intra_best{0u, X265AMD_MAX_SAD};
+    return x265amd_intra_best{key & 63u, key >> 6};
 }
 
 template <int N>
@@ -292,7 +402,7 @@ __global__ __launch_bounds__(256) void intra_decide_kernel(const uint8_t *__rest
     if (pred) {  // workgroup-uniform
         __syncthreads();
         const int bm = s_best;
-        const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][bm]];
+        const uint8_t *ref = s_ref[intra_filter<L2 - 2>(bm)];
         for (int i = tid; i < NPIX; i += 256)
             pred[(int64_t)cu * NPIX + i] = (uint8_t)intra_pixel<N>(ref, bm, i >> L2, i & (N - 1), dc);
     }
@@ -318,7 +428,12 @@ struct IntraWave {
     uint32_t lambda;
     int64_t fs_y, fs_c, fs_cu;  // a batch of independent frames (blockIdx.y): frame to frame, in elements, of the luma
                                 // planes, the chroma planes and the per-CU arrays
+    uint32_t *stats;            // x265amd_debug_set_intra_stats: 16 cycle stamps per (frame, CU), or null
 };
+// stamp i of this workgroup's CU (thread 0; block-uniform test)
+#define X265AMD_INTRA_STAMP(i) \
+    if (w.stats && threadIdx.x == 0) w.stats[((int64_t)blockIdx.y * w.ncx * w.ncy + cu) * 16 + (i)] = (uint32_t)clock64()
+
 
 // sample i of the reference array of an n x n block at (x0, y0) of plane `rec`: xEncIntraLoadRef + xPaddingRef
 __device__ __forceinline__ int intra_ref_sample(const uint8_t *rec, int stride, int x0, int y0, int n, int i, bool bL, bool bT, bool bTR)
@@ -365,18 +480,19 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
         if (f.d_cost_y) f.d_cost_y += ou;
         if (f.d_cost_c) f.d_cost_c += ou;
     }
-    __shared__ uint8_t s_ref[2][kMaxRef + 3];
-    __shared__ uint8_t s_refc[2][4 * 16 + 4];  // U, V: chroma reads the samples as they are
+    __shared__ __attribute__((aligned(16))) uint8_t s_ref[2][kRefRow], s_rev[2][kRefRow];  // the samples, smoothed; both in reverse
+    __shared__ __attribute__((aligned(16))) uint8_t s_refc[2][4 * 16 + 8], s_revc[2][4 * 16 + 8];  // U, V: chroma reads the samples as they are
     __shared__ __attribute__((aligned(16))) uint8_t s_main[NWAVES][2][kMainRow];
     __shared__ __attribute__((aligned(16))) uint8_t s_srcq[2][N][N + 4];  // the source CU, [row][column] and transposed
     __shared__ uint32_t s_sad[35], s_sadc[6];
-    __shared__ int s_dc, s_dcc[2], s_best, s_bestc, s_mpm[3];
+    __shared__ int s_dc, s_dcc[2], s_mpm[3];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cuy = w.cy_lo + blockIdx.x, cux = w.d - 2 * cuy;
     if (cux < 0 || cux >= w.ncx || cuy >= w.ncy) return false;  // block-uniform (the host sizes the grid to fit)
     const int x0 = cux * N, y0 = cuy * N, cu = cuy * w.ncx + cux;
     const bool bL = cux > 0, bT = cuy > 0, bTR = bT && cux + 1 < w.ncx;
+    X265AMD_INTRA_STAMP(0);
 
     // the lane's source pixels and the left neighbour's mode: asked for first, so that they travel together with the
     // reference samples (one memory latency instead of two)
@@ -420,9 +536,17 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
         s_refc[pl][j] = (uint8_t)intra_ref_sample(pl ? f.d_rec_v : f.d_rec_u, f.stride_c, x0 / 2, y0 / 2, NC, j, bL, bT, bTR);
     }
     __syncthreads();
+    X265AMD_INTRA_STAMP(1);
     if (tid <= 4 * N) {
         const int a = s_ref[0][tid];
-        s_ref[1][tid] = (tid == 0 || tid == 4 * N) ? (uint8_t)a : (uint8_t)((s_ref[0][tid - 1] + 2 * a + s_ref[0][tid + 1] + 2) >> 2);
+        const uint8_t sm = (tid == 0 || tid == 4 * N) ? (uint8_t)a : (uint8_t)((s_ref[0][tid - 1] + 2 * a + s_ref[0][tid + 1] + 2) >> 2);
+        s_ref[1][tid] = sm;
+        s_rev[0][4 * N - tid] = (uint8_t)a;
+        s_rev[1][4 * N - tid] = sm;
+    }
+    for (int i = tid; i < 2 * (4 * NC + 1); i += NT) {
+        const int pl = i >= 4 * NC + 1, j = i - pl * (4 * NC + 1);
+        s_revc[pl][4 * NC - j] = s_refc[pl][j];
     }
     if (wave == 0) intra_dc_value<N>(s_ref[0], lane, &s_dc);
     if (wave == 1) intra_dc_value<NC>(s_refc[0], lane, &s_dcc[0]);
@@ -444,8 +568,11 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
         s_mpm[0] = m0, s_mpm[1] = m1, s_mpm[2] = m2;
     }
     __syncthreads();
+    X265AMD_INTRA_STAMP(2);
 
-    // ---- luma decision ----
+    // ---- the SADs: 35 luma modes and, with them, the five chroma candidates that do not depend on the luma decision
+    //      (planar, vertical, horizontal, DC, and 34, which stands in for whichever of the four the luma mode equals:
+    //      src/encode.cpp:781-853), one list of 40 tasks dealt round the waves ----
     const int dc = s_dc;
     uint32_t srcv[PER / 4], srch[PER / 4];
 #pragma unroll
@@ -454,44 +581,17 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
         srcv[t] = *reinterpret_cast<const uint32_t *>(&s_srcq[0][q / (N / 4)][4 * (q % (N / 4))]);
         srch[t] = *reinterpret_cast<const uint32_t *>(&s_srcq[1][q / (N / 4)][4 * (q % (N / 4))]);
     }
-    intra_luma_sads_quads<N, PER, NWAVES>(s_ref, sp, srcv, srch, dc, wave, lane, s_sad, s_main[wave][0]);
-    __syncthreads();
-    if (tid == 0) {
-        const x265amd_intra_best b = intra_luma_argmin(s_sad, s_mpm[0], s_mpm[1], s_mpm[2], w.lambda);
-        s_best = (int)b.mode;
-        f.d_mode_y[cu] = (uint8_t)b.mode;
-        if (f.d_cost_y) f.d_cost_y[cu] = b.cost;
-    }
-    __syncthreads();
-    const int bm = s_best;
-    {
-        const uint8_t *ref = s_ref[kIntraFilter[L2 - 2][bm]];
-        for (int i = tid; i < NPIX; i += NT)
-            f.d_pred_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))] = (uint8_t)intra_pixel<N>(ref, bm, i >> L2, i & (N - 1), dc);
-    }
-
-    // ---- chroma decision (:781-853): candidates in the reference's order, the one equal to the luma mode replaced
-    //      by 34, LM (index 4) skipped; cost = SAD(U) + SAD(V); first strict minimum ----
-    auto cand_mode = [&](int k) -> int {
-        const int base[4] = {0, 26, 10, 1};
-        if (k == 5) return bm;
-        int firstdup = 4;
-        for (int j = 3; j >= 0; j--)
-            if (base[j] == bm) firstdup = j;
-        return k == firstdup ? 34 : base[k];
-    };
-    for (int k = wave; k < 6; k += NWAVES) {
-        if (k == 4) continue;  // wave-uniform
-        const int mode = cand_mode(k);
+    // SAD(U) + SAD(V) of chroma mode `mode` (wave-uniform), by one wave
+    auto chroma_sad = [&](int mode) __attribute__((always_inline)) -> uint32_t {
         uint32_t s = 0;
-        if (mode >= 2) {  // wave-uniform
-            intra_fill_main<NC>(s_refc[0], mode, lane, s_main[wave][0]);
-            intra_fill_main<NC>(s_refc[1], mode, lane, s_main[wave][1]);
+        if (mode >= 2) {
+            const uint8_t *ru = intra_main_row<NC>(mode < 18 ? s_revc[0] : s_refc[0], mode, lane, s_main[wave][0]);
+            const uint8_t *rv = intra_main_row<NC>(mode < 18 ? s_revc[1] : s_refc[1], mode, lane, s_main[wave][1]);
 #pragma unroll
             for (int t = 0; t < PERC; t++) {
                 const int i = lane + 64 * t;
-                s += (uint32_t)abs(su[t] - intra_ang_pixel<NC, false>(s_refc[0], s_main[wave][0], mode, i >> L2C, i & (NC - 1)));
-                s += (uint32_t)abs(sv[t] - intra_ang_pixel<NC, false>(s_refc[1], s_main[wave][1], mode, i >> L2C, i & (NC - 1)));
+                s += (uint32_t)abs(su[t] - intra_ang_pixel<NC, false>(s_refc[0], ru, mode, i >> L2C, i & (NC - 1)));
+                s += (uint32_t)abs(sv[t] - intra_ang_pixel<NC, false>(s_refc[1], rv, mode, i >> L2C, i & (NC - 1)));
             }
         } else {
 #pragma unroll
@@ -501,32 +601,76 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
                 s += (uint32_t)abs(sv[t] - intra_pixel<NC, false>(s_refc[1], mode, i >> L2C, i & (NC - 1), s_dcc[1]));
             }
         }
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) s_sadc[k] = s;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        uint32_t bc = X265AMD_MAX_SAD;
-        int bk = 0;
-        for (int k = 0; k < 6; k++) {
-            if (k == 4) continue;
-            if (s_sadc[k] < bc) {
-                bc = s_sadc[k];
-                bk = k;
-            }
+        return wave_sum_u32(s);
+    };
+    for (int task = wave; task < 40; task += NWAVES) {  // wave-uniform
+        if (task < 35) {
+            const uint32_t sd = intra_luma_sad_quads<N, PER>(s_ref, s_rev, sp, srcv, srch, dc, task, lane, s_main[wave][0]);
+            if (lane == 0) s_sad[task] = sd;
+        } else {
+            const int k = task - 35;  // s_sadc[0..3]: planar, vertical, horizontal, DC; [4]: mode 34
+            const uint32_t sd = chroma_sad(k == 0 ? 0 : k == 1 ? 26 : k == 2 ? 10 : k == 3 ? 1 : 34);
+            if (lane == 0) s_sadc[k] = sd;
         }
-        const int real = cand_mode(bk);
-        s_bestc = real;
-        f.d_mode_c[cu] = (uint8_t)real;
-        if (f.d_cost_c) f.d_cost_c[cu] = bc;
     }
     __syncthreads();
-    const int bmc = s_bestc;
+    X265AMD_INTRA_STAMP(3);
+    // ---- luma decision: every wave works it out for itself (no barrier to hand it round) ----
+    const x265amd_intra_best lb = intra_luma_argmin_wave(s_sad, s_mpm[0], s_mpm[1], s_mpm[2], w.lambda, lane);
+    const int bm = (int)lb.mode;
+    if (tid == 0) {
+        f.d_mode_y[cu] = (uint8_t)bm;
+        if (f.d_cost_y) f.d_cost_y[cu] = lb.cost;
+    }
+    X265AMD_INTRA_STAMP(4);
+    // the one chroma candidate that does depend on it: the luma mode itself, unless it is one of the five above
+    const bool known = bm == 0 || bm == 26 || bm == 10 || bm == 1 || bm == 34;
+    if (wave == NWAVES - 1 && !known) {
+        const uint32_t sd = chroma_sad(bm);
+        if (lane == 0) s_sadc[5] = sd;
+    }
+    {
+        const uint8_t *ref = s_ref[intra_filter<L2 - 2>(bm)];
+        for (int i = tid; i < NPIX; i += NT)
+            f.d_pred_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))] = (uint8_t)intra_pixel<N>(ref, bm, i >> L2, i & (N - 1), dc);
+    }
+    __syncthreads();
+    X265AMD_INTRA_STAMP(5);
+
+    // ---- chroma decision (:781-853): candidates in the reference's order -- planar, vertical, horizontal, DC with the one
+    //      equal to the luma mode replaced by 34, LM (index 4) skipped, then the luma mode; cost = SAD(U) + SAD(V); first
+    //      strict minimum.  Six numbers: every wave again for itself ----
+    int bmc;
+    {
+        const int base[4] = {0, 26, 10, 1};
+        uint32_t bc = X265AMD_MAX_SAD;
+        bmc = 0;  // candidate 0's mode, should nothing be under MAX_SAD
+        bool dup_seen = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool dup = base[k] == bm && !dup_seen;
+            dup_seen = dup_seen || dup;
+            const int mode = dup ? 34 : base[k];
+            const uint32_t c = dup ? s_sadc[4] : s_sadc[k];
+            if (k == 0) bmc = mode;
+            if (c < bc) bc = c, bmc = mode;
+        }
+        {   // candidate 5: the luma mode
+            const uint32_t c = bm == 0 ? s_sadc[0] : bm == 26 ? s_sadc[1] : bm == 10 ? s_sadc[2] : bm == 1 ? s_sadc[3] : bm == 34 ? s_sadc[4] : s_sadc[5];
+            if (c < bc) bc = c, bmc = bm;
+        }
+        if (tid == 0) {
+            f.d_mode_c[cu] = (uint8_t)bmc;
+            if (f.d_cost_c) f.d_cost_c[cu] = bc;
+        }
+    }
+    X265AMD_INTRA_STAMP(6);
     for (int i = tid; i < 2 * NPIXC; i += NT) {
         const int pl = i >= NPIXC, j = i - pl * NPIXC;
         const int64_t o = (int64_t)(y0 / 2 + (j >> L2C)) * f.stride_c + x0 / 2 + (j & (NC - 1));
         (pl ? f.d_pred_v : f.d_pred_u)[o] = (uint8_t)intra_pixel<NC, false>(s_refc[pl], bmc, j >> L2C, j & (NC - 1), s_dcc[pl]);
     }
+    X265AMD_INTRA_STAMP(7);
     return true;
 }
 
@@ -549,9 +693,12 @@ __global__ __launch_bounds__(NT, 1024 / NT) void intra_wave_tq_kernel(const Intr
     if (!intra_wave_body<N, NT>(w)) return;
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (wave == 0)
+    const int cu = (w.cy_lo + (int)blockIdx.x) * w.ncx + w.d - 2 * (w.cy_lo + (int)blockIdx.x);
+    X265AMD_INTRA_STAMP(8);
+    if (wave == 0) {
         tq_mfma_body<N, TQ_BOTH, false>(py, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, -1);
-    else if (wave <= 2)
+        X265AMD_INTRA_STAMP(9);
+    } else if (wave <= 2)
         tq_mfma_body<N / 2, TQ_BOTH, false>(pc, (int)blockIdx.x, (int)blockIdx.y * cby_mul + (wave == 2 ? cby_add : 0), (int)gridDim.x, -1);
 }
 
@@ -621,6 +768,7 @@ static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st
     w.ncy = f->height / f->cu;
     w.d = d;
     w.lambda = (uint32_t)f->qp;  // src/encode.cpp:597
+    w.stats = debug_state().intra_stats;
     // cux = d - 2 cuy in [0, ncx): cuy from ceil((d - ncx + 1) / 2) to d / 2
     const int lo = d - (w.ncx - 1) > 0 ? (d - (w.ncx - 1) + 1) / 2 : 0;
     const int hi = d / 2 < w.ncy - 1 ? d / 2 : w.ncy - 1;
@@ -653,6 +801,10 @@ static int intra_wave_launch(const x265amd_intra_frame *f, int d, hipStream_t st
     return hip_status(hipGetLastError());
 }
 
+extern "C" void x265amd_debug_set_intra_stats(uint32_t *d_stats)
+{
+    if (device_state()) debug_state().intra_stats = d_stats;
+}
 extern "C" void x265amd_debug_intra_fused(int on)
 {
     if (device_state()) debug_state().intra_fused = on;
