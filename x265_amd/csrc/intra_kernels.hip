@@ -233,13 +233,29 @@ __device__ __forceinline__ uint32_t intra_ang_quad(const uint8_t *row, int a, in
     const int sh = 8 * (a & 3);
     const uint32_t A = (uint32_t)(win >> sh), Bq = (uint32_t)(win >> (sh + 8));
     const uint32_t fp = (uint32_t)fact * 0x00010001u, gp = 0x00200020u - fp;
-    auto blend = [&](uint32_t x, uint32_t y) -> uint32_t {
-        const u16x2 r = (__builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, gp) + __builtin_bit_cast(u16x2, y) * __builtin_bit_cast(u16x2, fp) +
-                         __builtin_bit_cast(u16x2, 0x00100010u)) >> (unsigned short)5;
+    auto blend = [&](uint32_t x, uint32_t y) -> uint32_t {  // two multiply-adds: y * f + 16, then x * (32 - f) + that
+        const u16x2 t = __builtin_bit_cast(u16x2, y) * __builtin_bit_cast(u16x2, fp) + __builtin_bit_cast(u16x2, 0x00100010u);
+        const u16x2 r = (__builtin_bit_cast(u16x2, x) * __builtin_bit_cast(u16x2, gp) + t) >> (unsigned short)5;
         return __builtin_bit_cast(uint32_t, r);
     };
-    const uint32_t even = blend(A & 0x00ff00ffu, Bq & 0x00ff00ffu), odd = blend((A >> 8) & 0x00ff00ffu, (Bq >> 8) & 0x00ff00ffu);
+    // bytes 0, 2 and bytes 1, 3 of a dword as zero-extended u16 pairs: one v_perm_b32 each (selector 0x0c = a zero byte)
+    const uint32_t even = blend(__builtin_amdgcn_perm(0u, A, 0x0c020c00u), __builtin_amdgcn_perm(0u, Bq, 0x0c020c00u));
+    const uint32_t odd = blend(__builtin_amdgcn_perm(0u, A, 0x0c030c01u), __builtin_amdgcn_perm(0u, Bq, 0x0c030c01u));
     return even | (odd << 8);
+}
+
+// Four neighbouring pixels of the planar mode (src/encode.cpp:1353-1396): row k, columns x0 .. x0 + 3; top[j] = the sample
+// above column x0 + j.  ((left << L2) + N + (c + 1)(tr - left) + (top << L2) + (r + 1)(bl - top)) >> (L2 + 1)
+//   = (base + j dh + top_j (N - 1 - r)) >> (L2 + 1),  base = (left << L2) + N + (r + 1) bl + (x0 + 1) dh,  dh = tr - left.
+template <int N> __device__ __forceinline__ uint32_t intra_planar_quad(const uint8_t *tl, int k, int x0, const int (&top)[4], int tr, int bl)
+{
+    constexpr int L2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+    const int left = tl[-1 - k], dh = tr - left, wn = N - 1 - k;
+    const int base = (left << L2) + N + __mul24(k + 1, bl) + __mul24(x0 + 1, dh);
+    uint32_t pq = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) pq |= (uint32_t)(((__mul24(top[j], wn) + base + j * dh) >> (L2 + 1)) & 0xff) << (8 * j);
+    return pq;
 }
 
 // ---- pieces shared by the two kernels (one workgroup per CU) ----
@@ -285,9 +301,9 @@ __device__ __forceinline__ void intra_luma_sads(const uint8_t (*s_ref)[kMaxRef +
 // The same for the frame kernel's 16 / 32 wide CUs, four pixels a step (intra_ang_quad): srcv[t] = the source pixels of
 // quad q = lane + 64 t read along rows (line k = q / (N / 4), x0 = 4 (q % (N / 4)): row k, columns x0 ..), srch[t] = the
 // same quad of the TRANSPOSED source (column k, rows x0 ..) -- a mode below 18 is the mirrored construction, so it is
-// compared against the transposed block.  Planar and DC take the pixel path.
+// compared against the transposed block.  Planar and DC are put together a quad at a time too.
 template <int N, int PER>
-__device__ __forceinline__ uint32_t intra_luma_sad_quads(const uint8_t (*s_ref)[kRefRow], const uint8_t (*s_rev)[kRefRow], const int (&sp)[PER],
+__device__ __forceinline__ uint32_t intra_luma_sad_quads(const uint8_t (*s_ref)[kRefRow], const uint8_t (*s_rev)[kRefRow],
                                                          const uint32_t (&srcv)[PER / 4], const uint32_t (&srch)[PER / 4], int dc, int mode,
                                                          int lane, uint8_t *row_buf)
 {
@@ -300,24 +316,56 @@ __device__ __forceinline__ uint32_t intra_luma_sad_quads(const uint8_t (*s_ref)[
         const int ang = intra_angle(mode);
         const bool hor = mode < 18;
         const uint8_t *main_row = intra_main_row<N>(hor ? s_rev[filt] : ref, mode, lane, row_buf);
+        if (ang != 0) {  // wave-uniform
+#pragma unroll
+            for (int t = 0; t < PER / 4; t++) {
+                const int q = lane + 64 * t, k = q / QL, x0 = 4 * (q % QL);
+                const int pos = __mul24(k + 1, ang);
+                s = __builtin_amdgcn_sad_u8(intra_ang_quad(main_row, N + x0 + (pos >> 5) + 1, pos & 31), hor ? srch[t] : srcv[t], s);
+            }
+        } else {  // modes 10 and 26: every line is the main side itself; its first pixel follows the other side's gradient
+            const uint8_t *tl = ref + 2 * N;
+#pragma unroll
+            for (int t = 0; t < PER / 4; t++) {
+                const int q = lane + 64 * t, k = q / QL, x0 = 4 * (q % QL);
+                uint32_t pq = intra_ang_quad(main_row, N + x0 + 1, 0);
+                if (x0 == 0) {
+                    const int p = (int)(pq & 0xffu) + ((tl[(hor ? 1 : -1) * (k + 1)] - tl[0]) >> 1);
+                    pq = (pq & 0xffffff00u) | (uint32_t)min(max(p, 0), 255);
+                }
+                s = __builtin_amdgcn_sad_u8(pq, hor ? srch[t] : srcv[t], s);
+            }
+        }
+    } else if (mode == 1) {
+        // DC: the value everywhere but on the first row and column, which lean on the samples beside them
+        // (src/encode.cpp:1418-1444) -- a quad is four copies of dc, or, in row 0 / for the first pixel of a row, smoothed
+        const uint8_t *tl = ref + 2 * N;
+        const uint32_t dc4 = (uint32_t)dc * 0x01010101u;
 #pragma unroll
         for (int t = 0; t < PER / 4; t++) {
             const int q = lane + 64 * t, k = q / QL, x0 = 4 * (q % QL);
-            const int pos = (k + 1) * ang;
-            uint32_t pq = intra_ang_quad(main_row, N + x0 + (pos >> 5) + 1, pos & 31);
-            if (ang == 0 && x0 == 0) {  // modes 10 and 26: the first pixel of a line follows the other side's gradient
-                const uint8_t *tl = ref + 2 * N;
-                const int p = (int)(pq & 0xffu) + ((tl[(hor ? 1 : -1) * (k + 1)] - tl[0]) >> 1);
-                pq = (pq & 0xffffff00u) | (uint32_t)min(max(p, 0), 255);
+            uint32_t pq = dc4;
+            if (k == 0) {
+                pq = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) pq |= (uint32_t)((tl[1 + x0 + j] + 3 * dc + 2) >> 2) << (8 * j);
+                if (x0 == 0) pq = (pq & 0xffffff00u) | (uint32_t)((tl[1] + tl[-1] + 2 * dc + 2) >> 2);
+            } else if (x0 == 0) {
+                pq = (pq & 0xffffff00u) | (uint32_t)((tl[-1 - k] + 3 * dc + 2) >> 2);
             }
-            s = __builtin_amdgcn_sad_u8(pq, hor ? srch[t] : srcv[t], s);
+            s = __builtin_amdgcn_sad_u8(pq, srcv[t], s);
         }
     } else {
+        // planar: a lane's quads all lie in the same four columns (64 is a multiple of the quads per line)
+        const uint8_t *tl = ref + 2 * N;
+        const int tr = tl[1 + N], bl = tl[-1 - N];
+        const int x0 = 4 * (lane % QL);
+        int top[4];
 #pragma unroll
-        for (int t = 0; t < PER; t++) {
-            const int i = lane + 64 * t;
-            s = sad_acc((uint32_t)sp[t], (uint32_t)intra_pixel<N>(ref, mode, i >> L2, i & (N - 1), dc), s);
-        }
+        for (int j = 0; j < 4; j++) top[j] = tl[1 + x0 + j];
+#pragma unroll
+        for (int t = 0; t < PER / 4; t++)
+            s = __builtin_amdgcn_sad_u8(intra_planar_quad<N>(tl, lane / QL + (64 / QL) * t, x0, top, tr, bl), srcv[t], s);
     }
     return wave_sum_u32(s);
 }
@@ -470,7 +518,7 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
     constexpr int L2 = N == 16 ? 4 : 5;
     constexpr int NC = N / 2, L2C = L2 - 1;
     constexpr int NPIX = N * N, PER = NPIX / 64;
-    constexpr int NPIXC = NC * NC, PERC = NPIXC / 64;
+    constexpr int NPIXC = NC * NC;
     x265amd_intra_frame f = w.f;
     {   // this workgroup's frame of the batch (block-uniform: scalar address arithmetic)
         const int64_t oy = (int64_t)blockIdx.y * w.fs_y, oc = (int64_t)blockIdx.y * w.fs_c, ou = (int64_t)blockIdx.y * w.fs_cu;
@@ -484,6 +532,7 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
     __shared__ __attribute__((aligned(16))) uint8_t s_refc[2][4 * 16 + 8], s_revc[2][4 * 16 + 8];  // U, V: chroma reads the samples as they are
     __shared__ __attribute__((aligned(16))) uint8_t s_main[NWAVES][2][kMainRow];
     __shared__ __attribute__((aligned(16))) uint8_t s_srcq[2][N][N + 4];  // the source CU, [row][column] and transposed
+    __shared__ __attribute__((aligned(16))) uint8_t s_srcc[2][2][NC][NC + 4];  // its chroma: [U, V][as it is, transposed]
     __shared__ uint32_t s_sad[35], s_sadc[6];
     __shared__ int s_dc, s_dcc[2], s_mpm[3];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -494,25 +543,18 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
     const bool bL = cux > 0, bT = cuy > 0, bTR = bT && cux + 1 < w.ncx;
     X265AMD_INTRA_STAMP(0);
 
-    // the lane's source pixels and the left neighbour's mode: asked for first, so that they travel together with the
-    // reference samples (one memory latency instead of two)
-    int sp[PER];
-#pragma unroll
-    for (int t = 0; t < PER; t++) {
-        const int i = lane + 64 * t;
-        sp[t] = f.d_src_y[(int64_t)(y0 + (i >> L2)) * f.stride_y + x0 + (i & (N - 1))];
-    }
-    int su[PERC], sv[PERC];
-#pragma unroll
-    for (int t = 0; t < PERC; t++) {
-        const int i = lane + 64 * t;
-        const int64_t o = (int64_t)(y0 / 2 + (i >> L2C)) * f.stride_c + x0 / 2 + (i & (NC - 1));
-        su[t] = f.d_src_u[o];
-        sv[t] = f.d_src_v[o];
-    }
+    // The source CU, a pixel per thread, and the left neighbour's mode: asked for first, so that they travel together
+    // with the reference samples (one memory latency instead of two).  The source goes to LDS by rows and by columns, luma
+    // and chroma: the quads of four pixels that the SADs compare against are aligned dwords there whatever the plane's
+    // stride and address.
     const int left_mode = (tid == NT - 1 && bL) ? f.d_mode_y[cu - 1] : 1;
-    // the source once more, a pixel per thread: laid out in LDS by rows and by columns, the quads of four pixels that
-    // intra_luma_sads_quads compares against are aligned dwords there whatever the plane's stride and address
+    constexpr int TPC = (2 * NPIXC + NT - 1) / NT;
+    int cpix[TPC];
+#pragma unroll
+    for (int t = 0; t < TPC; t++) {
+        const int i = tid + NT * t, pl = i >= NPIXC, j = i - pl * NPIXC;
+        cpix[t] = i < 2 * NPIXC ? (pl ? f.d_src_v : f.d_src_u)[(int64_t)(y0 / 2 + (j >> L2C)) * f.stride_c + x0 / 2 + (j & (NC - 1))] : 0;
+    }
     constexpr int TP = (NPIX + NT - 1) / NT;
     int tpix[TP];
 #pragma unroll
@@ -528,6 +570,14 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
         if (i < NPIX) {
             s_srcq[0][i >> L2][i & (N - 1)] = (uint8_t)tpix[t];
             s_srcq[1][i & (N - 1)][i >> L2] = (uint8_t)tpix[t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TPC; t++) {
+        const int i = tid + NT * t, pl = i >= NPIXC, j = i - pl * NPIXC;
+        if (i < 2 * NPIXC) {
+            s_srcc[pl][0][j >> L2C][j & (NC - 1)] = (uint8_t)cpix[t];
+            s_srcc[pl][1][j & (NC - 1)][j >> L2C] = (uint8_t)cpix[t];
         }
     }
     if (tid <= 4 * N) s_ref[0][tid] = (uint8_t)intra_ref_sample(f.d_rec_y, f.stride_y, x0, y0, N, tid, bL, bT, bTR);
@@ -581,31 +631,47 @@ __device__ __forceinline__ bool intra_wave_body(const IntraWave &w)
         srcv[t] = *reinterpret_cast<const uint32_t *>(&s_srcq[0][q / (N / 4)][4 * (q % (N / 4))]);
         srch[t] = *reinterpret_cast<const uint32_t *>(&s_srcq[1][q / (N / 4)][4 * (q % (N / 4))]);
     }
-    // SAD(U) + SAD(V) of chroma mode `mode` (wave-uniform), by one wave
+    // SAD(U) + SAD(V) of chroma mode `mode` (wave-uniform), by one wave, a quad of four pixels a lane and step like luma
+    // (no edge smoothing for chroma: bLuma = false in the reference's calls)
     auto chroma_sad = [&](int mode) __attribute__((always_inline)) -> uint32_t {
-        uint32_t s = 0;
+        constexpr int QLC = NC / 4, NQC = NPIXC / 4;  // quads per line, per plane (64 at CU 32, 16 at CU 16)
+        const bool hor = mode >= 2 && mode < 18;
+        const int ang = intra_angle(mode);
+        const uint8_t *rows[2] = {nullptr, nullptr};
         if (mode >= 2) {
-            const uint8_t *ru = intra_main_row<NC>(mode < 18 ? s_revc[0] : s_refc[0], mode, lane, s_main[wave][0]);
-            const uint8_t *rv = intra_main_row<NC>(mode < 18 ? s_revc[1] : s_refc[1], mode, lane, s_main[wave][1]);
+            rows[0] = intra_main_row<NC>(hor ? s_revc[0] : s_refc[0], mode, lane, s_main[wave][0]);
+            rows[1] = intra_main_row<NC>(hor ? s_revc[1] : s_refc[1], mode, lane, s_main[wave][1]);
+        }
+        uint32_t s = 0;
 #pragma unroll
-            for (int t = 0; t < PERC; t++) {
-                const int i = lane + 64 * t;
-                s += (uint32_t)abs(su[t] - intra_ang_pixel<NC, false>(s_refc[0], ru, mode, i >> L2C, i & (NC - 1)));
-                s += (uint32_t)abs(sv[t] - intra_ang_pixel<NC, false>(s_refc[1], rv, mode, i >> L2C, i & (NC - 1)));
-            }
-        } else {
+        for (int t = 0; t < (NQC + 63) / 64; t++) {
+            const int q = lane + 64 * t;
+            const bool on = q < NQC;
+            const int qc = on ? q : 0, k = qc / QLC, x0 = 4 * (qc % QLC);
 #pragma unroll
-            for (int t = 0; t < PERC; t++) {
-                const int i = lane + 64 * t;
-                s += (uint32_t)abs(su[t] - intra_pixel<NC, false>(s_refc[0], mode, i >> L2C, i & (NC - 1), s_dcc[0]));
-                s += (uint32_t)abs(sv[t] - intra_pixel<NC, false>(s_refc[1], mode, i >> L2C, i & (NC - 1), s_dcc[1]));
+            for (int pl = 0; pl < 2; pl++) {
+                uint32_t pq;
+                if (mode >= 2) {
+                    const int pos = __mul24(k + 1, ang);
+                    pq = intra_ang_quad(rows[pl], NC + x0 + (pos >> 5) + 1, pos & 31);
+                } else if (mode == 1) {
+                    pq = (uint32_t)s_dcc[pl] * 0x01010101u;
+                } else {
+                    const uint8_t *tl = s_refc[pl] + 2 * NC;
+                    int top[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) top[j] = tl[1 + x0 + j];
+                    pq = intra_planar_quad<NC>(tl, k, x0, top, tl[1 + NC], tl[-1 - NC]);
+                }
+                const uint32_t sq = *reinterpret_cast<const uint32_t *>(&s_srcc[pl][hor ? 1 : 0][k][x0]);
+                if (on) s = __builtin_amdgcn_sad_u8(pq, sq, s);
             }
         }
         return wave_sum_u32(s);
     };
     for (int task = wave; task < 40; task += NWAVES) {  // wave-uniform
         if (task < 35) {
-            const uint32_t sd = intra_luma_sad_quads<N, PER>(s_ref, s_rev, sp, srcv, srch, dc, task, lane, s_main[wave][0]);
+            const uint32_t sd = intra_luma_sad_quads<N, PER>(s_ref, s_rev, srcv, srch, dc, task, lane, s_main[wave][0]);
             if (lane == 0) s_sad[task] = sd;
         } else {
             const int k = task - 35;  // s_sadc[0..3]: planar, vertical, horizontal, DC; [4]: mode 34
