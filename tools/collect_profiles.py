@@ -53,7 +53,7 @@ def main():
     if os.path.exists(p):
         shutil.copy(p, os.path.join(DST, f"{rnd}_pmc_sq_intra1080p.json"))
         n += 1
-    for name in ("pu_bench", "intra_bench", "tq_trace", "encode_i_bench", "sea_stats", "noise_split"):
+    for name in ("pu_bench", "intra_bench", "tq_trace", "encode_i_bench", "sea_stats", "noise_split", "intra_stats", "host_pcie", "gop_steps"):
         p = os.path.join(SRC, name + ".txt")
         if os.path.exists(p):
             with open(p) as i, open(os.path.join(DST, f"{rnd}_{name}.txt"), "w") as o:

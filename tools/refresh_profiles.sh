@@ -26,6 +26,9 @@ bench)
   timeout -k 10 400 bash tools/encode_i_bench.sh > $OUT/encode_i_bench.txt 2>&1; echo "encode_i done"
   timeout -k 10 100 python tools/sea_stats.py 16 > $OUT/sea_stats.txt 2>&1; echo "sea stats done"
   timeout -k 10 100 python tools/noise_split.py > $OUT/noise_split.txt 2>&1; echo "noise split done"
+  (timeout -k 10 100 python tools/intra_stats.py 1 && timeout -k 10 100 python tools/intra_stats.py 16) > $OUT/intra_stats.txt 2>&1; echo "intra stats done"
+  timeout -k 10 300 bash tools/host_bench.sh > $OUT/host_pcie.txt 2>&1; echo "host bench done"
+  timeout -k 10 100 python tools/gop_steps.py 8 pingpong > $OUT/gop_steps.txt 2>&1; echo "gop steps done"
   ;;
 trace)
   cd /tmp && export TMPDIR=/tmp
