@@ -85,9 +85,11 @@ struct Batch {  // one batch of segments: its encoder, its stream, its pinned bu
 
 // nbatch = 1: upload, kernels, download strictly one after the other.  nbatch = 2, 4: the segments split into
 // batches on streams of their own, so that one batch's PCIe copies run under the others' kernels.
-// (Waiting for a batch only when its next picture is due, so that the batches drift apart, was measured too and
-// gains nothing: DESIGN.md section 5.)
-static void bench_one(const std::vector<uint8_t> &file, int w, int h, int nframes, int qp, int range, int nseg, int nbatch, int mode)
+// threads: every batch on a host thread of its own, so that no batch's next picture waits for another batch's sync --
+// with the kernels writing the results into host memory themselves (mode 2) this is what lets uploads run under
+// kernels picture after picture.
+// X265AMD_BENCH_ONLY=mode,streams [X265AMD_BENCH_THREADS=1]: one configuration only (tools/host_prof.sh's traces).
+static void bench_one(const std::vector<uint8_t> &file, int w, int h, int nframes, int qp, int range, int nseg, int nbatch, int mode, bool threads = false)
 {
     const bool packed = mode >= 1;  // mode 2: the kernels write the packed levels into the host's memory themselves
 
@@ -116,6 +118,37 @@ static void bench_one(const std::vector<uint8_t> &file, int w, int h, int nframe
         counted = rep > 0;
         for (auto &b : bs) b->enc->set_reference(b->up->as());
         for (auto &b : bs) b->enc->sync();
+        if (threads) {  // every batch on a host thread of its own: picture after picture, nobody waits for anybody
+            const auto t0 = std::chrono::steady_clock::now();
+            std::vector<std::thread> th;
+            std::vector<std::exception_ptr> err(bs.size());
+            for (size_t i = 0; i < bs.size(); i++)
+                th.emplace_back([&, i] {
+                    try {
+                        check(x265amd_init(0), "x265amd_init");  // the device is per thread
+                        for (int t = 1; t < nframes; t++) {
+                            bs[i]->go(t);
+                            bs[i]->finish();
+                        }
+                    } catch (...) {
+                        err[i] = std::current_exception();
+                    }
+                });
+            for (auto &t : th) t.join();
+            for (auto &e : err)
+                if (e) std::rethrow_exception(e);
+            const double ms = since(t0) / (nframes - 1);
+            if (counted)
+                for (auto &b : bs)
+                    down_total += (nframes - 1) * (packed ? 4.0 * b->words_down + b->table->bytes() + b->mv->bytes()
+                                                          : (double)(b->lvl->bytes() + b->mv->bytes() + b->cbf->bytes()));
+            if (rep) {
+                best = ms < best ? ms : best;
+                total += ms * (nframes - 1);
+                pics += nframes - 1;
+            }
+            continue;
+        }
         for (int t = 1; t < nframes; t++) {
             const auto t0 = std::chrono::steady_clock::now();
             for (auto &b : bs) b->go(t);
@@ -129,10 +162,10 @@ static void bench_one(const std::vector<uint8_t> &file, int w, int h, int nframe
         }
     }
     const double mpix = (double)w * h * nseg / 1e6;
-    printf("{\"host\": \"c++\", \"pcie_inclusive\": true, \"levels\": \"%s\", \"width\": %d, \"height\": %d, \"nseg\": %d, "
+    printf("{\"host\": \"%s\", \"pcie_inclusive\": true, \"levels\": \"%s\", \"width\": %d, \"height\": %d, \"nseg\": %d, "
            "\"streams\": %d, \"pictures\": %d, \"ms_per_step_mean\": %.4f, \"ms_per_step_best\": %.4f, \"mpixels_per_s_mean\": %.1f, "
            "\"bytes_up_per_step\": %zu, \"bytes_down_per_step\": %.0f}\n",
-           mode == 2 ? "packed_direct" : packed ? "packed" : "dense", w, h, nseg, nbatch, pics, total / pics, best,
+           threads ? "c++, a thread per stream" : "c++", mode == 2 ? "packed_direct" : packed ? "packed" : "dense", w, h, nseg, nbatch, pics, total / pics, best,
            mpix / (total / pics) * 1e3, fsz * nseg, down_total / pics);
 }
 
@@ -146,10 +179,18 @@ static int bench(char **a)
         File in(a[0], "rb");
         if (fread(file.data(), 1, file.size(), in.f) != file.size()) throw std::runtime_error("short read");
     }
+    if (const char *only = getenv("X265AMD_BENCH_ONLY")) {  // "mode,streams": one configuration (for traces)
+        bench_one(file, w, h, nframes, qp, range, nseg, atoi(strchr(only, ',') ? strchr(only, ',') + 1 : "1"), atoi(only),
+                  getenv("X265AMD_BENCH_THREADS") != nullptr);
+        return 0;
+    }
     for (int mode = 0; mode < 3; mode++) {  // the levels as dense planes, then as x265amd_pack_levels leaves them (copied / written direct)
         bench_one(file, w, h, nframes, qp, range, nseg, 1, mode);
-        for (int nb = 2; nb <= 4; nb *= 2)
-            if (nseg % nb == 0 && nseg >= 2 * nb - 2) bench_one(file, w, h, nframes, qp, range, nseg, nb, mode);
+        for (int nb = 2; nb <= 8; nb *= 2)
+            if (nseg % nb == 0 && nseg >= 2 * nb - 2 && (nb < 8 || mode)) {
+                bench_one(file, w, h, nframes, qp, range, nseg, nb, mode);
+                if (mode) bench_one(file, w, h, nframes, qp, range, nseg, nb, mode, true);
+            }
     }
     return 0;
 }

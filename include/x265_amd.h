@@ -91,9 +91,12 @@ int x265amd_free_host(void *h_ptr);
 int x265amd_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes, void *stream);
 int x265amd_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes, void *stream);
 /* Device memory into page-locked host memory (x265amd_malloc_host's; anything else is X265AMD_ERR_ARG) by a kernel
- * of `stream` that stores across the link, instead of by the copy engine: for the small things that come down
- * after the kernels of a picture (vectors, counts), where a copy-engine transfer costs more in set-up than in
- * bytes.  bytes and both pointers multiples of 4.  The reference has no device boundary and nothing like it. */
+ * of `stream` that stores across the link, instead of by the copy engine.  For what comes down after the kernels
+ * of a picture when several streams are at work: a copy-engine download queued behind its stream's kernels keeps
+ * the uploads of the OTHER streams from starting until that stream has drained (measured: host/encode_p.cpp
+ * --bench, DESIGN.md section 5 -- 14 Gpixels/s with such downloads, 23 with kernels writing the results);
+ * a kernel holds up nothing.  bytes and both pointers multiples of 4.  The reference has no device boundary and
+ * nothing like it. */
 int x265amd_copy_to_host(void *h_dst, const void *d_src, size_t bytes, void *stream);
 int x265amd_stream_sync(void *stream);
 /* a hipStream_t for hosts without HIP headers: two batches of segments on two streams overlap one batch's

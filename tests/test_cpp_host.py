@@ -89,7 +89,10 @@ def test_cpp_host_bench_mode_streams_and_pinned_memory(gpu, tmp_path):
                        timeout=120)
     assert r.returncode == 0, r.stderr
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert [(l["levels"], l["streams"]) for l in lines] == [(lv, st) for lv in ("dense", "packed", "packed_direct") for st in (1, 2)]
+    want = [("dense", 1, "c++"), ("dense", 2, "c++")]
+    for lv in ("packed", "packed_direct"):
+        want += [(lv, 1, "c++"), (lv, 2, "c++"), (lv, 2, "c++, a thread per stream")]
+    assert [(l["levels"], l["streams"], l["host"]) for l in lines] == want
     assert lines[2]["bytes_down_per_step"] < lines[0]["bytes_down_per_step"]
     for l in lines:
         assert l["pcie_inclusive"] and l["nseg"] == 2 and l["mpixels_per_s_mean"] > 0
