@@ -32,8 +32,8 @@ def main():
             continue
         name = os.path.basename(d)[len("trace_"):]
         stats = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
-        if stats:
-            shutil.copy(stats[0], os.path.join(DST, f"{rnd}_{name}_kernel_stats.csv"))
+        if stats:  # earlier refreshes leave their files beside the new ones (named by process id): the newest counts
+            shutil.copy(max(stats, key=os.path.getmtime), os.path.join(DST, f"{rnd}_{name}_kernel_stats.csv"))
             n += 1
     p = os.path.join(SRC, "pmc_traffic.json")
     if os.path.exists(p):
