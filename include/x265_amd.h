@@ -413,7 +413,8 @@ int x265amd_dequant_plane(const int16_t *d_level, int16_t *d_coef, int stride, i
  *   d_abs_sum                     optional: xQuant's per-TU sums as the transform entry points leave them; a TU whose sum
  *                                 is 0 is entered as empty without being read
  * d_tu_table and d_words may be page-locked host memory (x265amd_malloc_host): the words then cross the link as
- * they are written and there is nothing to copy afterwards (d_cursor stays in device memory: it is an atomic).
+ * they are written and there is nothing to copy afterwards (d_cursor stays in device memory: it is an atomic);
+ * ordinary (pageable) host memory is refused with X265AMD_ERR_ARG.
  * Any stride works; planes whose rows start on 16-byte boundaries (d_level, 2 * stride, 2 * frame_stride multiples
  * of 16) take the fast path with one 16-byte load per lane. */
 int x265amd_pack_levels_begin(uint32_t *d_cursor, void *stream);

@@ -131,6 +131,12 @@ def test_pack_levels_capacity_and_arguments(gpu):
             nz = np.flatnonzero(blk)
             np.testing.assert_array_equal(wd[off:off + cnt].view(np.uint32) >> 16, nz)
             np.testing.assert_array_equal((wd[off:off + cnt] & 0xffff).astype(np.uint16).view(np.int16), blk[nz])
+    # the table / the words in ordinary host memory: an error code, not a GPU fault
+    from x265_amd import api
+    host_words = np.zeros(need, np.int32)
+    st = api._lib().x265amd_pack_levels(d.data_ptr(), 64, 64, 64, 8, 1, 0, None, 0, table.data_ptr(), host_words.ctypes.data, need,
+                                        cursor.data_ptr(), None)
+    assert st == -1, st  # X265AMD_ERR_ARG
     with pytest.raises(gpu.X265AmdError):
         gpu.pack_levels(d, 12)
     with pytest.raises(gpu.X265AmdError):

@@ -144,6 +144,18 @@ __global__ __launch_bounds__(256) void pack_levels_kernel(const PackParams p)
 
 using namespace x265amd;
 
+// The header invites page-locked host memory for the table and the words: make sure that what came is memory a kernel can
+// write (device, or host memory the runtime has mapped) -- a pageable host pointer here would be a GPU fault, not an error code.
+static bool kernel_can_write(const void *p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged;
+}
+
 extern "C" int x265amd_pack_levels_begin(uint32_t *d_cursor, void *stream)
 {
     if (!initialised()) return X265AMD_ERR_NOT_INIT;
@@ -162,6 +174,7 @@ extern "C" int x265amd_pack_levels(const int16_t *d_level, int width, int height
     if (width <= 0 || height <= 0 || width % tu || height % tu || stride < width || nframes < 0) return X265AMD_ERR_ARG;
     if ((uintptr_t)d_level & 1) return X265AMD_ERR_ARG;
     if (nframes == 0) return X265AMD_OK;
+    if (!kernel_can_write(d_tu_table) || (capacity && !kernel_can_write(d_words))) return X265AMD_ERR_ARG;
     PackParams p;
     p.level = d_level;
     p.abs_sum = d_abs_sum;
