@@ -141,3 +141,26 @@ def test_pack_levels_capacity_and_arguments(gpu):
         gpu.pack_levels(d, 12)
     with pytest.raises(gpu.X265AmdError):
         gpu.pack_levels(torch.zeros((1, 60, 64), dtype=torch.int16, device="cuda"), 8)
+
+
+def test_copy_to_host_by_kernel(gpu):
+    """x265amd_copy_to_host: device memory into page-locked host memory by a kernel of the stream; anything that is not
+    page-locked host memory is refused."""
+    import ctypes as C
+    from x265_amd import api
+    lib = api._lib()
+    for n in (4, 20, 4096, 1 << 20):  # bytes: the 4-byte path (20) and the 16-byte one
+        src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
+        hp = C.c_void_p()
+        assert lib.x265amd_malloc_host(C.byref(hp), n) == 0
+        try:
+            assert lib.x265amd_copy_to_host(hp, src.data_ptr(), n, None) == 0
+            torch.cuda.synchronize()
+            got = np.frombuffer((C.c_uint8 * n).from_address(hp.value), np.uint8)
+            np.testing.assert_array_equal(got, src.cpu().numpy())
+        finally:
+            lib.x265amd_free_host(hp)
+    pageable = np.zeros(64, np.uint8)
+    src = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    assert lib.x265amd_copy_to_host(pageable.ctypes.data, src.data_ptr(), 64, None) == -1
+    assert lib.x265amd_copy_to_host(pageable.ctypes.data, src.data_ptr(), 6, None) == -1  # not a multiple of 4
