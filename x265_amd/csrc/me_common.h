@@ -28,5 +28,65 @@ __host__ __device__ inline void me_qsad_layout(int w, int h, int range, int cx, 
     win_rows = blk + kMeT * ngy;
 }
 
+// Reductions over the 64 lanes of a wave without the LDS crossbar: four DPP steps inside the rows of 16 lanes (pairs,
+// quads, half rows, rows), then the four row results through v_readlane -- every lane gets the answer.  ALL 64 lanes
+// must be active at the call.  (A __shfl_xor ladder is six dependent ds_bpermute trips, twelve for a 64-bit key:
+// about a thousand cycles on the critical path of every round of the exact kernel.)
+template <int CTRL> __device__ __forceinline__ uint32_t me_dpp(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ uint32_t me_rows4_min(uint32_t s)
+{
+    return min(min((uint32_t)__builtin_amdgcn_readlane((int)s, 0), (uint32_t)__builtin_amdgcn_readlane((int)s, 16)),
+               min((uint32_t)__builtin_amdgcn_readlane((int)s, 32), (uint32_t)__builtin_amdgcn_readlane((int)s, 48)));
+}
+__device__ __forceinline__ uint32_t me_wave_min_u32(uint32_t s)
+{
+    s = min(s, me_dpp<0xb1>(s));   // quad_perm [1,0,3,2]
+    s = min(s, me_dpp<0x4e>(s));   // quad_perm [2,3,0,1]
+    s = min(s, me_dpp<0x141>(s));  // row_half_mirror
+    s = min(s, me_dpp<0x140>(s));  // row_mirror
+    return me_rows4_min(s);
+}
+__device__ __forceinline__ uint32_t me_wave_max_u32(uint32_t s)
+{
+    s = max(s, me_dpp<0xb1>(s));
+    s = max(s, me_dpp<0x4e>(s));
+    s = max(s, me_dpp<0x141>(s));
+    s = max(s, me_dpp<0x140>(s));
+    return max(max((uint32_t)__builtin_amdgcn_readlane((int)s, 0), (uint32_t)__builtin_amdgcn_readlane((int)s, 16)),
+               max((uint32_t)__builtin_amdgcn_readlane((int)s, 32), (uint32_t)__builtin_amdgcn_readlane((int)s, 48)));
+}
+__device__ __forceinline__ uint32_t me_wave_sum_u32(uint32_t s)
+{
+    s += me_dpp<0xb1>(s);
+    s += me_dpp<0x4e>(s);
+    s += me_dpp<0x141>(s);
+    s += me_dpp<0x140>(s);
+    return (uint32_t)__builtin_amdgcn_readlane((int)s, 0) + (uint32_t)__builtin_amdgcn_readlane((int)s, 16) +
+           (uint32_t)__builtin_amdgcn_readlane((int)s, 32) + (uint32_t)__builtin_amdgcn_readlane((int)s, 48);
+}
+// inclusive prefix sum over the lanes of a wave: shifts by 1, 2, 4, 8 inside the rows (a lane without a source gets 0),
+// then the totals of the rows before the lane's own through v_readlane.  ALL 64 lanes active.
+__device__ __forceinline__ uint32_t me_wave_scan_u32(uint32_t s, int lane)
+{
+    s += me_dpp<0x111>(s);  // row_shr:1
+    s += me_dpp<0x112>(s);  // row_shr:2
+    s += me_dpp<0x114>(s);  // row_shr:4
+    s += me_dpp<0x118>(s);  // row_shr:8
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)s, 15), t1 = (uint32_t)__builtin_amdgcn_readlane((int)s, 31),
+                   t2 = (uint32_t)__builtin_amdgcn_readlane((int)s, 47);
+    return s + (lane >= 16 ? t0 : 0u) + (lane >= 32 ? t1 : 0u) + (lane >= 48 ? t2 : 0u);
+}
+// minimum of 64-bit keys (sad << 32 | index): the smallest upper half first, then the smallest lower half among the
+// lanes that hold it -- two 32-bit reductions, fewer registers and instructions than 64-bit compares and selects
+__device__ __forceinline__ unsigned long long me_wave_min_u64(unsigned long long k)
+{
+    const uint32_t hi = (uint32_t)(k >> 32);
+    const uint32_t m = me_wave_min_u32(hi);
+    const uint32_t lo = me_wave_min_u32(hi == m ? (uint32_t)k : 0xffffffffu);
+    return ((unsigned long long)m << 32) | lo;
+}
 
 }  // namespace x265amd

@@ -239,8 +239,11 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
         uint32_t s = 0;
 #pragma unroll
         for (int k = 0; k < S / 4; k++) s = __builtin_amdgcn_sad_u8(p[k], 0u, s);
-#pragma unroll
-        for (int o = 1; o < S; o <<= 1) s += __shfl_xor(s, o);
+        // the S lanes of a sub-block lie inside one row of 16 lanes (whole waves are here: 16 * S is a multiple of 64)
+        s += me_dpp<0xb1>(s);
+        s += me_dpp<0x4e>(s);
+        if constexpr (S >= 8) s += me_dpp<0x141>(s);
+        if constexpr (S >= 16) s += me_dpp<0x140>(s);
         if (rrow == 0) csum[b] = s;
     }
     __syncthreads();
@@ -355,10 +358,8 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
             }
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) my_min = min(my_min, (uint32_t)__shfl_xor((int)my_min, o));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) my_max = max(my_max, (uint32_t)__shfl_xor((int)my_max, o));
+    my_min = me_wave_min_u32(my_min);
+    my_max = me_wave_max_u32(my_max);
     if (lane == 0 && my_min != 0xffffffffu) {
         atomicMin(&min_key, my_min);
         atomicMax(&max_st, my_max);
@@ -371,24 +372,14 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
     //      quota comes from pick_bin itself, whichever of its groups the scan reaches first ----
     if (tid < 64) {
         uint32_t c0 = hist[tid], c1 = (tid + 64 < kBins) ? hist[tid + 64] : 0u;
-        uint32_t s0 = c0;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(s0, o);
-            if (lane >= o) s0 += t;
-        }
-        const uint32_t tot0 = __shfl(s0, 63);
-        uint32_t s1 = c1;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(s1, o);
-            if (lane >= o) s1 += t;
-        }
-        s1 += tot0;
+        const uint32_t s0 = me_wave_scan_u32(c0, lane);
+        const uint32_t tot0 = (uint32_t)__builtin_amdgcn_readlane((int)s0, 63);
+        const uint32_t s1 = me_wave_scan_u32(c1, lane) + tot0;
         const unsigned long long m0 = __ballot(s0 >= (uint32_t)nfirst), m1 = __ballot(s1 >= (uint32_t)nfirst && tid + 64 < kBins);
         const int pbv = m0 ? __ffsll((long long)m0) - 1 : (m1 ? 64 + __ffsll((long long)m1) - 1 : kBins);
-        const uint32_t incl = pbv < 64 ? __shfl(s0, pbv & 63) : __shfl(s1, pbv & 63);  // count through pick_bin
-        const uint32_t own = pbv < 64 ? __shfl(c0, pbv & 63) : __shfl(c1, pbv & 63);
+        const int pl = __builtin_amdgcn_readfirstlane(pbv & 63);  // (wave-uniform: it comes from ballots)
+        const uint32_t incl = (uint32_t)__builtin_amdgcn_readlane((int)(pbv < 64 ? s0 : s1), pl);  // count through pick_bin
+        const uint32_t own = (uint32_t)__builtin_amdgcn_readlane((int)(pbv < 64 ? c0 : c1), pl);
         pref[tid] = s0;
         if (tid + 64 < kBins) pref[tid + 64] = s1;
         if (tid == 0) {
@@ -442,9 +433,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
             if (lane >= B) acc16 = 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                uint32_t sq = (uint32_t)(acc16 >> (16 * q)) & 0xffffu;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) sq += (uint32_t)__shfl_xor((int)sq, o);
+                const uint32_t sq = me_wave_sum_u32((uint32_t)(acc16 >> (16 * q)) & 0xffffu);
                 const int dxi = 4 * gx + q - a;
                 if (dxi >= 0 && dxi < ndx) {
                     const unsigned long long k = ((unsigned long long)sq << 32) |
@@ -473,8 +462,8 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
             if (me) we = atomicAdd(&eq_n, __popcll(me));
         }
         const unsigned long long lt = (1ull << lane) - 1ull;
-        const int sl = __shfl(wl, 0) + __popcll(mb & lt);  // next slot among the groups under pb
-        const int se = __shfl(we, 0) + __popcll(me & lt);  // rank within bin pb (both read lane 0: outside any branch)
+        const int sl = __builtin_amdgcn_readfirstlane(wl) + __popcll(mb & lt);  // next slot among the groups under pb
+        const int se = __builtin_amdgcn_readfirstlane(we) + __popcll(me & lt);  // rank within bin pb (both read lane 0: outside any branch)
         const bool take = below || (equal && se < quota);
         const int slot = equal ? nbelow + se : sl;
         if (take) {
@@ -484,8 +473,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
             rest_min = min(rest_min, v);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) rest_min = min(rest_min, (uint32_t)__shfl_xor((int)rest_min, o));
+    rest_min = me_wave_min_u32(rest_min);
     if (lane == 0 && rest_min != kNone) atomicMin(&rest_lb, rest_min);
     __syncthreads();
     // (what lies past a block's last group in its last 16 bytes is never looked at: kernel 2 checks the index)
@@ -513,12 +501,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
             cnt += gt;
             msk |= gt << b;
         }
-        uint32_t inc = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
-        }
+        const uint32_t inc = me_wave_scan_u32(cnt, lane);
         rank_base[tid] = inc - cnt;
         rank_mask[tid] = msk;
     }
@@ -834,7 +817,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         if (km != 0ull) {
             int wbase = 0;
             if (lane == 0) wbase = atomicAdd(&surv_n, __popcll(km));
-            wbase = __shfl(wbase, 0);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
             if (keep) {
                 const int slot = wbase + __popcll(km & ((1ull << lane) - 1ull));
                 surv_ent[slot] = (uint16_t)ent;
@@ -868,11 +851,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                         }
                     }
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const unsigned long long other = __shfl_xor(k, o);
-                    k = other < k ? other : k;
-                }
+                k = me_wave_min_u64(k);
                 if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
             }
             round++;  // the next half round writes the other half of part[]: no second barrier
@@ -916,11 +895,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                     }
                 }
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned long long other = __shfl_xor(k, o);
-                k = other < k ? other : k;
-            }
+            k = me_wave_min_u64(k);
             if (lane == 0 && k != ~0ull) atomicMin(&best_key, k);
         }
         round++;
@@ -939,9 +914,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             p0 = half_sum();
             pmin0 = legal_min(ent0, p0);
         }
-        uint32_t wm = pmin0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) wm = min(wm, (uint32_t)__shfl_xor((int)wm, o));
+        const uint32_t wm = me_wave_min_u32(pmin0);
         if (lane == 0) atomicMin(&u_min, wm);
     }
     round++;
@@ -1006,16 +979,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
             const uint32_t tm0 = takers(wv0, vi0), tm1 = takers(wv1, vi1);
             if (__ballot((tm0 | tm1) != 0u) == 0ull) continue;  // wave-uniform
             const int cnt = __popc(tm0) + __popc(tm1);
-            int inc = cnt;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(inc, o);
-                if (lane >= o) inc += t;
-            }
-            const int tot = __shfl(inc, 63);
+            const int inc = (int)me_wave_scan_u32((uint32_t)cnt, lane);
+            const int tot = __builtin_amdgcn_readlane(inc, 63);
             int wbase = 0;
             if (lane == 0) wbase = atomicAdd(&list_n, tot);
-            int slot = __shfl(wbase, 0) + inc - cnt;
+            int slot = __builtin_amdgcn_readfirstlane(wbase) + inc - cnt;
 #pragma unroll
             for (int e = 0; e < 8; e++)
                 if (tm0 & (1u << e)) list[slot++] = (uint16_t)(8 * vi0 + e);
