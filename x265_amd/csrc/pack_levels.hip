@@ -10,6 +10,7 @@
 // HBM-bound in the worst case (every level read once: 2 B per sample); with the per-TU sums that the transform
 // stage already wrote, a TU without a level is not even read.
 #include "common.h"
+#include "me_common.h"  // the DPP wave scan
 
 namespace x265amd {
 
@@ -31,7 +32,7 @@ struct PackParams {
 // room ONCE for all it holds -- the cursor is one address, and an atomic per TU was what the kernel's time consisted
 // of (11 ns each, one after the other) -- writes the table entries of those TUs and lets the words go a lane per
 // word: the stores to HBM are contiguous whatever the TUs' patterns are.
-constexpr int kTusPerWave = 8;
+constexpr int kTusPerWave = 16;
 constexpr int kStageWords = 2048;  // per wave; >= 32 * 32, the largest TU
 
 template <int N, bool ALIGNED>
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void pack_levels_kernel(const PackParams p)
         if (held == 0) return;  // wave-uniform
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(p.cursor, used);  // keeps counting past the capacity: the host sees what was needed
-        base = (uint32_t)__shfl((int)base, 0);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
         if (lane < held) {
             p.table[2 * my_k] = base + my_off;
             p.table[2 * my_k + 1] = my_cnt;
@@ -68,57 +69,78 @@ __global__ __launch_bounds__(256) void pack_levels_kernel(const PackParams p)
         used = 0, held = 0;
     };
 
-#pragma unroll 1
-    for (int it = 0; it < kTusPerWave; it++) {
-        const int64_t k = k0 + it;
-        if (k >= ntotal) break;
-        const int f = (int)(k / p.ntu), t = (int)(k - (int64_t)f * p.ntu);
-        if (p.abs_sum && p.abs_sum[(int64_t)f * p.abs_sum_frame_stride + t] == 0u) {  // wave-uniform: nothing coded here
-            if (lane == 0) p.table[2 * k] = 0u, p.table[2 * k + 1] = 0u;
-            continue;
+    // The TUs' sums, all at once (lane i: TU k0 + i): which of them are coded is known before the first level is read.
+    uint32_t my_sum = 0;
+    if (lane < kTusPerWave && k0 + lane < ntotal) {
+        my_sum = 1u;
+        if (p.abs_sum) {
+            const int64_t kk = k0 + lane;
+            const int f = (int)(kk / p.ntu), t = (int)(kk - (int64_t)f * p.ntu);
+            my_sum = p.abs_sum[(int64_t)f * p.abs_sum_frame_stride + t];
         }
+    }
+    // the lane's chunks of TU k, as they lie in memory (pairs of levels per dword); zeros where the lane has no chunk
+    auto load_tu = [&](int64_t k, uint32_t (&raw)[PASSES][CH / 2]) __attribute__((always_inline)) {
+        const int f = (int)(k / p.ntu), t = (int)(k - (int64_t)f * p.ntu);
         const int ty = t / p.tus_x, tx = t - ty * p.tus_x;
         const int16_t *tu0 = p.level + f * p.frame_stride + (int64_t)(ty * N) * p.stride + tx * N;
-        int v[PASSES][CH];
-        uint32_t packed = 0;
 #pragma unroll
         for (int ps = 0; ps < PASSES; ps++) {
             const int c = lane + 64 * ps;
 #pragma unroll
-            for (int j = 0; j < CH; j++) v[ps][j] = 0;
+            for (int j = 0; j < CH / 2; j++) raw[ps][j] = 0u;
             if (c < NCH) {
                 const int16_t *src = tu0 + (int64_t)(c / CPR) * p.stride + (c % CPR) * CH;
                 if constexpr (ALIGNED) {  // rows of the TU start on CH * 2-byte boundaries (the entry point checked)
-                    uint32_t w[CH / 2];
                     if constexpr (CH == 8) {
                         const uint4 q = *reinterpret_cast<const uint4 *>(src);
-                        w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+                        raw[ps][0] = q.x, raw[ps][1] = q.y, raw[ps][2] = q.z, raw[ps][3] = q.w;
                     } else {
                         const uint2 q = *reinterpret_cast<const uint2 *>(src);
-                        w[0] = q.x, w[1] = q.y;
-                    }
-#pragma unroll
-                    for (int j = 0; j < CH / 2; j++) {
-                        v[ps][2 * j] = (int)(int16_t)(w[j] & 0xffffu);
-                        v[ps][2 * j + 1] = (int)(int16_t)(w[j] >> 16);
+                        raw[ps][0] = q.x, raw[ps][1] = q.y;
                     }
                 } else {
 #pragma unroll
-                    for (int j = 0; j < CH; j++) v[ps][j] = src[j];
+                    for (int j = 0; j < CH / 2; j++) raw[ps][j] = (uint32_t)(uint16_t)src[2 * j] | ((uint32_t)(uint16_t)src[2 * j + 1] << 16);
                 }
             }
+        }
+    };
+    // One TU ahead: the loads of the next coded TU are in flight while this one is counted, scanned and staged (a wave
+    // walks its TUs one after the other; without this each of them cost a memory latency of its own).
+    uint32_t nxt[PASSES][CH / 2];
+    const int ntus = (int)min((int64_t)kTusPerWave, ntotal - k0);
+    const unsigned long long coded = __ballot(my_sum != 0u);  // bit i: TU k0 + i has levels (or is not known not to)
+    int it = coded ? __ffsll((long long)coded) - 1 : ntus;
+    if (lane < ntus && my_sum == 0u) p.table[2 * (k0 + lane)] = 0u, p.table[2 * (k0 + lane) + 1] = 0u;
+    if (it < ntus) load_tu(k0 + it, nxt);
+#pragma unroll 1
+    while (it < ntus) {
+        const int64_t k = k0 + it;
+        uint32_t raw[PASSES][CH / 2];
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++)
+#pragma unroll
+            for (int j = 0; j < CH / 2; j++) raw[ps][j] = nxt[ps][j];
+        const unsigned long long rest = it + 1 < 64 ? coded >> (it + 1) : 0ull;
+        it = rest ? it + 1 + (__ffsll((long long)rest) - 1) : ntus;
+        if (it < ntus) load_tu(k0 + it, nxt);
+        int v[PASSES][CH];
+        uint32_t packed = 0;
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ps++) {
             uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < CH / 2; j++) {
+                v[ps][2 * j] = (int)(int16_t)(raw[ps][j] & 0xffffu);
+                v[ps][2 * j + 1] = (int)(int16_t)(raw[ps][j] >> 16);
+            }
 #pragma unroll
             for (int j = 0; j < CH; j++) cnt += v[ps][j] != 0;
             packed |= cnt << (16 * ps);  // at most 8 * 64 = 512 a pass: the two counts scan as one word
         }
-        uint32_t inc = packed;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = (uint32_t)__shfl_up((int)inc, o);
-            if (lane >= o) inc += u;
-        }
-        const uint32_t tot = (uint32_t)__shfl((int)inc, 63), tot0 = tot & 0xffffu, total = tot0 + (tot >> 16);
+        const uint32_t inc = me_wave_scan_u32(packed, lane);  // (all 64 lanes are here: the branches above are wave-uniform)
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), tot0 = tot & 0xffffu, total = tot0 + (tot >> 16);
         if (total == 0) {  // wave-uniform
             if (lane == 0) p.table[2 * k] = 0u, p.table[2 * k + 1] = 0u;
             continue;
