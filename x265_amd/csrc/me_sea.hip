@@ -753,6 +753,46 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                 if (e < total_dw) win[e] = v[j];
             }
         }
+    } else if (WAVES == 8 && L.pitch <= 64) {
+        // a row is at most 64 dwords: 16 bytes a lane, several rows per load instruction of a wave (13 chunks a row
+        // at +-64: four rows), and all of a wave's instructions in flight at once -- the whole window for ONE memory
+        // latency (a lane per dword took two batches of 13 rows).  Rows start on dword boundaries only, which a
+        // four-dword load takes; a chunk that reaches past the right edge of the picture goes dword by dword.
+        struct __attribute__((packed, aligned(4))) Dw4 {
+            uint32_t v[4];
+        };
+        const int nch = (L.pitch + 3) >> 2, rpi = 64 / nch;  // chunks per row (<= 16), rows per instruction (>= 4)
+        const int sub = lane / nch, ch = lane - sub * nch;
+        const bool lane_on = sub < rpi;
+        const int gx = L.wx0 + 16 * ch;
+        constexpr int kChunksInFlight = 6;
+        for (int r0 = wave * rpi; r0 < L.win_rows; r0 += WAVES * rpi * kChunksInFlight) {
+            Dw4 v[kChunksInFlight];
+#pragma unroll
+            for (int j = 0; j < kChunksInFlight; j++) {
+                const int row = r0 + WAVES * rpi * j + sub, gy = cy + L.dylo + row;
+                v[j] = Dw4{{0u, 0u, 0u, 0u}};  // outside the picture: only ever paired with candidates that are masked below
+                if (lane_on && row < L.win_rows && gy < g.height) {
+                    const uint8_t *p = ref + (int64_t)gy * g.stride + gx;
+                    if (gx + 16 <= g.width) {
+                        v[j] = *reinterpret_cast<const Dw4 *>(p);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (gx + 4 * k + 4 <= g.width) v[j].v[k] = *reinterpret_cast<const uint32_t *>(p + 4 * k);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kChunksInFlight; j++) {
+                const int row = r0 + WAVES * rpi * j + sub;
+                if (lane_on && row < L.win_rows) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (4 * ch + k < L.pitch) win[row * L.pitch + 4 * ch + k] = v[j].v[k];
+                }
+            }
+        }
     } else
     for (int qb = 0; qb < L.pitch; qb += 64) {
         const int wq = qb + lane;
