@@ -943,6 +943,78 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     using SeaLowerHalves = std::integral_constant<bool, true>;
     using SeaWholeBlocks = std::integral_constant<bool, false>;
 
+    // ---- a handful of groups: a LANE PER ROW.  A wave takes one group (whole blocks of 64 rows) or 64 / rows of them, a
+    //      lane one row of it: NW window dwords + 1 from LDS, the row of the current block from memory (16 bytes a
+    //      load; the block is in the caches from the rounds before), NW qsads, and the rows are added up across the
+    //      lanes by DPP.  The split round above costs eight (four) rows' worth of qsads at a quarter of the rate with one
+    //      lane in 64 at work -- 11 000 (5 000) cycles for the one or two groups that tier 1 or a light second pass
+    //      brings; this costs one row's worth.  Same arguments and barriers as split_round; part[] is not touched. ----
+    auto rows_round = [&](auto lower_c, int from, int to) __attribute__((always_inline)) {
+        constexpr bool kLower = decltype(lower_c)::value;
+        constexpr int RW = kLower ? B / 2 : B;  // rows = lanes per group: 64, 32 or 16
+        constexpr int GPW = 64 / RW;            // groups per wave
+        constexpr int NW = B / 4;
+        struct __attribute__((packed, aligned(4))) Dw4 {
+            uint32_t v[4];
+        };
+        const int sub = lane / RW, rin = lane - sub * RW, row = (kLower ? B / 2 : 0) + rin;
+        for (int g0 = from; g0 < to; g0 += WAVES * GPW) {  // block-uniform bounds
+            const int li = g0 + wave * GPW + sub;
+            const bool have = li < to;
+            const int ent = have ? (int)(kLower ? surv_ent[li] : list[li]) : 0;
+            const int dyi = ent / L.ngx, gx = ent - dyi * L.ngx;
+            const uint32_t *wrow = win + (dyi + row) * L.pitch + gx;
+            const Dw4 *crow = reinterpret_cast<const Dw4 *>(cbase + row * cstr);
+            uint32_t d[NW + 1], c[NW];
+#pragma unroll
+            for (int k = 0; k < NW / 4; k++) {
+                const Dw4 t = crow[k];
+#pragma unroll
+                for (int j = 0; j < 4; j++) c[4 * k + j] = t.v[j];
+            }
+#pragma unroll
+            for (int k = 0; k < NW + 1; k++) d[k] = wrow[k];
+            uint64_t acc = 0;  // a row's four SADs: at most 64 * 255 each
+#pragma unroll
+            for (int k = 0; k < NW; k++) acc = __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)d[k + 1] << 32) | d[k], c[k], acc);
+            uint32_t sad[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t v = (uint32_t)(acc >> (16 * q)) & 0xffffu;
+                v += me_dpp<0xb1>(v);
+                v += me_dpp<0x4e>(v);
+                v += me_dpp<0x141>(v);
+                v += me_dpp<0x140>(v);  // the sum of the lane's row of 16 lanes, in each of them
+                if constexpr (RW > 16) {
+                    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16),
+                                   r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+                    v = RW == 64 ? r0 + r1 + r2 + r3 : (lane < 32 ? r0 + r1 : r2 + r3);
+                }
+                sad[q] = v;
+            }
+            if (have && rin == 0) {  // the group's first lane: its winner so far
+                if constexpr (kLower) {
+                    const uint4 up = *reinterpret_cast<const uint4 *>(&surv_sum[4 * li]);
+                    sad[0] += up.x, sad[1] += up.y, sad[2] += up.z, sad[3] += up.w;
+                }
+                const int dy = L.dylo + dyi;
+                unsigned long long k = ~0ull;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int dx = L.wx0 - cx + 4 * gx + q;
+                    if (dx >= L.dxlo && dx <= L.dxhi) {
+                        const unsigned long long key = ((unsigned long long)sad[q] << 32) | (unsigned)((dy + R) * span + dx + R);
+                        k = key < k ? key : k;
+                    }
+                }
+                if (k != ~0ull) atomicMin(&best_key, k);
+            }
+        }
+    };
+    // up to this many groups go a lane per row (whole blocks / lower halves); above: split_round, above 64: half rounds
+    // (two sweeps of the workgroup; four or eight measured the same on the headline and no better in the closed loop)
+    constexpr int kRowsWhole = 2 * WAVES, kRowsLower = 2 * WAVES * (B >= 64 ? 2 : 4);
+
     // ---- pass 0: the first batch.  Upper halves of all of it ... ----
     const bool have0 = slot0 < n0;
     half_partial(ent0, have0, (B / 4) * hq);
@@ -976,8 +1048,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         const int nk = surv_n;
         if (nk - nk2 > 64)
             lower_rounds(nk2, nk);
-        else if (nk > nk2)
+        else if (nk - nk2 > kRowsLower)
             split_round(SeaLowerHalves{}, nk2, nk);
+        else if (nk > nk2)
+            rows_round(SeaLowerHalves{}, nk2, nk);
         nk2 = nk;
         __syncthreads();
     }
@@ -1039,7 +1113,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
         // them.  A schedule of one set of lanes goes through whole, its rows split over the waves.
         int base = 0;
         if (n1 <= 64) {
-            split_round(SeaWholeBlocks{}, 0, n1);
+            if (n1 <= kRowsWhole)
+                rows_round(SeaWholeBlocks{}, 0, n1);
+            else
+                split_round(SeaWholeBlocks{}, 0, n1);
             base = n1;
             if constexpr (kStats) n_kept += n1;
             __syncthreads();
@@ -1071,8 +1148,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
                 if constexpr (kStats) n_kept += kept;
                 if (kept > 64)
                     lower_rounds(0, kept);
-                else if (kept > 0)
+                else if (kept > kRowsLower)
                     split_round(SeaLowerHalves{}, 0, kept);
+                else if (kept > 0)
+                    rows_round(SeaLowerHalves{}, 0, kept);
                 __syncthreads();  // every wave is done with the kept list; best_key is visible
                 if (tid == 0) surv_n = 0;
                 __syncthreads();
