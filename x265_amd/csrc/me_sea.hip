@@ -394,7 +394,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
 
     const long long tb3 = stats ? clock64() : 0;
     // ---- the first batch is picked out of the bounds in LDS -- a lane per group, consecutive groups to consecutive
-    //      lanes, a wave reserves its list slots with ONE LDS atomic per counter per sweep -- and marked there; the
+    //      lanes; count, one scan and one atomic per counter and wave, then take -- and marked there; the
     //      smallest bound left over goes to the header.  Then the bounds go out as they stand, 16 bytes per lane. ----
     uint16_t *glo = gl + ctu_id * gl_pitch;
     uint16_t *lo = list0 + ctu_id * gl_pitch;
@@ -446,31 +446,43 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
             probe_sad = (uint32_t)(ubk >> 32);
             probe_idx = (uint32_t)ubk;
         }
-    } else
-    for (int g0 = 0; g0 < L.ngroups; g0 += kBoundsThreads - 64) {
-        if (g0 + (wtid & ~63) >= L.ngroups) break;  // nothing left for this wave (wave-uniform; no barrier inside)
-        const int gi = g0 + wtid;
-        const uint32_t v = gi < L.ngroups ? (uint32_t)glb[gi] : kNone;
-        const bool valid = v != kNone;
-        const int bin = valid ? lb_bin(v) : kBins + 1;
-        const bool below = bin < pb;                   // pb == kBins: every legal group
-        const bool equal = bin == pb && pb < kBins;
-        const unsigned long long mb = __ballot(below), me = __ballot(equal);
+    } else {
+        // The other seven waves, a lane per group and sweep, in two passes over the bounds in LDS: first every lane COUNTS
+        // its groups under the pick bin and in it, one wave scan and one atomic per counter and wave hand out the slots,
+        // then the lanes go over their groups again and take them.  (A ballot, two atomics and their round trips per sweep
+        // made this selection as expensive as the bounds themselves -- half of the kernel at +-128.)
+        constexpr int kSweep = kBoundsThreads - 64;
+        uint32_t cnt = 0;  // groups under the pick bin | groups in it << 16  (at most 74 sweeps: the sums fit 16 bits)
+        for (int gi = wtid; gi < L.ngroups; gi += kSweep) {
+            const uint32_t v = (uint32_t)glb[gi];
+            if (v != kNone) {
+                const int bin = lb_bin(v);
+                cnt += (bin < pb ? 1u : 0u) + (bin == pb ? 0x10000u : 0u);  // pb == kBins: every legal group is under it
+            }
+        }
+        const uint32_t inc = me_wave_scan_u32(cnt, lane), tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         int wl = 0, we = 0;
         if (lane == 0) {
-            if (mb) wl = atomicAdd(&list_n, __popcll(mb));
-            if (me) we = atomicAdd(&eq_n, __popcll(me));
+            if (tot & 0xffffu) wl = atomicAdd(&list_n, (int)(tot & 0xffffu));
+            if (tot >> 16) we = atomicAdd(&eq_n, (int)(tot >> 16));
         }
-        const unsigned long long lt = (1ull << lane) - 1ull;
-        const int sl = __builtin_amdgcn_readfirstlane(wl) + __popcll(mb & lt);  // next slot among the groups under pb
-        const int se = __builtin_amdgcn_readfirstlane(we) + __popcll(me & lt);  // rank within bin pb (both read lane 0: outside any branch)
-        const bool take = below || (equal && se < quota);
-        const int slot = equal ? nbelow + se : sl;
-        if (take) {
-            sel_ent[slot] = (uint16_t)gi;  // schedule entry = the group's index dyi * ngx + gx
-            glb[gi] = (uint16_t)kNone;     // scheduled
-        } else if (valid) {
-            rest_min = min(rest_min, v);
+        int sl = __builtin_amdgcn_readfirstlane(wl) + (int)((inc - cnt) & 0xffffu);  // the lane's next slot among the groups under pb
+        int se = __builtin_amdgcn_readfirstlane(we) + (int)((inc - cnt) >> 16);      // its next rank within bin pb
+        for (int gi = wtid; gi < L.ngroups; gi += kSweep) {
+            const uint32_t v = (uint32_t)glb[gi];
+            if (v == kNone) continue;
+            const int bin = lb_bin(v);
+            const bool below = bin < pb, equal = bin == pb;
+            const bool take = below || (equal && se < quota);
+            const int slot = equal ? nbelow + se : sl;
+            sl += below ? 1 : 0;
+            se += equal ? 1 : 0;
+            if (take) {
+                sel_ent[slot] = (uint16_t)gi;  // schedule entry = the group's index dyi * ngx + gx
+                glb[gi] = (uint16_t)kNone;     // scheduled
+            } else {
+                rest_min = min(rest_min, v);
+            }
         }
     }
     rest_min = me_wave_min_u32(rest_min);
