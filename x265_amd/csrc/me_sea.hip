@@ -744,25 +744,44 @@ __global__ __launch_bounds__(WAVES * 64, 4) void sea_exact_kernel(const uint8_t 
     // ---- stage the reference window: a wave per row, a lane per dword, 13 rows in flight ----
     constexpr int kWinInFlight = 13;
     if (WAVES == 16 && L.pitch > 64) {  // (the 8-wave shape never sees such a window: it would not fit twice into the LDS)
-        // a row wider than a wave (+-128: 83 dwords): the window as ONE run of win_rows x pitch dwords dealt over the whole
-        // workgroup, so that no load instruction goes out with a quarter of its lanes (a second column pass would)
-        const int total_dw = L.win_rows * L.pitch;
-        const uint32_t recip = 0xffffffffu / (uint32_t)L.pitch + 1u;  // e / pitch = (e * recip) >> 32 for e < 2^16 x pitch
-        for (int e0 = tid; e0 < total_dw; e0 += kThreads * kWinInFlight) {
-            uint32_t v[kWinInFlight];
+        // a row wider than a wave (+-128: 83 dwords): the window as ONE run of 16-byte chunks (21 a row) dealt over the
+        // whole workgroup -- seven loads a lane, all in flight at once: one memory latency for the window.  This shape has
+        // the compute unit to itself, so nothing else runs under its staging.  Rows start on dword boundaries only, which a
+        // four-dword load takes; a chunk that reaches past the right edge of the picture goes dword by dword.
+        struct __attribute__((packed, aligned(4))) Dw4 {
+            uint32_t v[4];
+        };
+        constexpr int kChunks = 7;
+        const int nch = (L.pitch + 3) >> 2, total_ch = L.win_rows * nch;
+        const uint32_t recip = 0xffffffffu / (uint32_t)nch + 1u;  // e / nch = (e * recip) >> 32 for e < 2^16 x nch
+        for (int e0 = tid; e0 < total_ch; e0 += kThreads * kChunks) {
+            Dw4 v[kChunks];
 #pragma unroll
-            for (int j = 0; j < kWinInFlight; j++) {
+            for (int j = 0; j < kChunks; j++) {
                 const int e = e0 + kThreads * j;
-                const int row = (int)__umulhi((uint32_t)e, recip), wq = e - row * L.pitch;
-                const int gx = L.wx0 + 4 * wq, gy = cy + L.dylo + row;
-                v[j] = 0;
-                if (e < total_dw && gx + 4 <= g.width && gy < g.height)
-                    v[j] = *reinterpret_cast<const uint32_t *>(ref + (int64_t)gy * g.stride + gx);
+                const int row = (int)__umulhi((uint32_t)e, recip), ch = e - row * nch;
+                const int gx = L.wx0 + 16 * ch, gy = cy + L.dylo + row;
+                v[j] = Dw4{{0u, 0u, 0u, 0u}};
+                if (e < total_ch && gy < g.height) {
+                    const uint8_t *p = ref + (int64_t)gy * g.stride + gx;
+                    if (gx + 16 <= g.width) {
+                        v[j] = *reinterpret_cast<const Dw4 *>(p);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (gx + 4 * k + 4 <= g.width) v[j].v[k] = *reinterpret_cast<const uint32_t *>(p + 4 * k);
+                    }
+                }
             }
 #pragma unroll
-            for (int j = 0; j < kWinInFlight; j++) {
+            for (int j = 0; j < kChunks; j++) {
                 const int e = e0 + kThreads * j;
-                if (e < total_dw) win[e] = v[j];
+                const int row = (int)__umulhi((uint32_t)e, recip), ch = e - row * nch;
+                if (e < total_ch) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (4 * ch + k < L.pitch) win[row * L.pitch + 4 * ch + k] = v[j].v[k];
+                }
             }
         }
     } else if (WAVES == 8 && L.pitch <= 64) {
