@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void me_pu_kernel(const uint8_t *__restrict
 
     // ---- winners ----
     constexpr bool kKey16 = 16 + IDXB <= 32;  // does the 16x16 SAD (<= 65280) fit a single-dword key?
+    constexpr bool kKeyPk = IDXB == 16;       // keys cut straight out of the packed sums
     uint32_t k8[4], k168[2], k816[2], k16 = 0xffffffffu;  // keys: sad << IDXB | raster index
     uint32_t bs[5], bi[5];  // (sad, index) pairs: 16x16 when it has no key, the 2:1 PU and the block at 32, the same at 64
 #pragma unroll
@@ -149,58 +150,85 @@ __global__ __launch_bounds__(256, 2) void me_pu_kernel(const uint8_t *__restrict
                 oky64r = (unsigned)(cy + oy64r + dy) <= (unsigned)(H - h64r);
                 oky64 = (unsigned)(cy + dy) <= (unsigned)(H - 64);
             }
+            // a lane meets its candidates in raster order: strict < keeps the first
+            auto paired = [&](int i, uint32_t sad, uint32_t idx, bool ok) {
+                if (ok && sad < bs[i]) {
+                    bs[i] = sad;
+                    bi[i] = idx;
+                }
+            };
+            uint32_t s32[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const int dx = dxb + q;
-                const bool inr = valid && dx >= -R && dx <= R;
+                const bool inr = valid && (unsigned)(dx + R) <= (unsigned)(2 * R);
                 const uint32_t idx = idxrow + (uint32_t)dx;  // (dy + R) * span + dx + R
+                // kKeyPk: the key is the SAD's own 16-bit field of the packed sums above the 16-bit index -- one instruction
+                // (v_lshl_or_b32 / v_and_or_b32) -- and a displacement outside the range carries 0xffff there instead,
+                // above every SAD (<= 0xff00), through the index it is or-ed with
+                const uint32_t idxp = (kKeyPk && !inr) ? (idx | 0xffff0000u) : idx;
                 auto fld = [&](uint64_t v) { return (uint32_t)(v >> (16 * q)) & 0xffffu; };
-                bool okx0 = true, okx1 = true, okx01 = true, okx32r = true, okx32 = true, okx64r = true, okx64 = true;
+                bool okx0 = true, okx1 = true, okx01 = true, okx32r = true;
                 if constexpr (BORDER) {
                     const int X = cx + 16 * kq + dx;
                     okx0 = (unsigned)X <= (unsigned)(W - 8);
                     okx1 = (unsigned)(X + 8) <= (unsigned)(W - 8);
                     okx01 = (unsigned)X <= (unsigned)(W - 16);
                     okx32r = (unsigned)(cx + ox32r + dx) <= (unsigned)(W - w32r);
+                }
+                auto keyed = [&](uint32_t &best, uint64_t v, bool ok) {
+                    uint32_t key;
+                    if constexpr (kKeyPk) {
+                        const uint32_t dw = q < 2 ? (uint32_t)v : (uint32_t)(v >> 32);
+                        key = (q & 1) ? ((dw & 0xffff0000u) | idxp) : ((dw << 16) | idxp);
+                        if constexpr (BORDER) key = ok ? key : 0xffffffffu;
+                    } else {
+                        key = (fld(v) << IDXB) + idx;
+                        key = (inr && ok) ? key : 0xffffffffu;
+                    }
+                    best = min(best, key);
+                };
+                keyed(k8[0], acc[0][0], okx0 && oky0);
+                keyed(k8[1], acc[0][1], okx1 && oky0);
+                keyed(k8[2], acc[1][0], okx0 && oky1);
+                keyed(k8[3], acc[1][1], okx1 && oky1);
+                keyed(k168[0], h8[0], okx01 && oky0);
+                keyed(k168[1], h8[1], okx01 && oky1);
+                keyed(k816[0], v8[0], okx0 && oky01);
+                keyed(k816[1], v8[1], okx1 && oky01);
+                const uint32_t a = fld(s16);
+                if constexpr (kKey16)
+                    keyed(k16, s16, okx01 && oky01);
+                else
+                    paired(0, a, idx, inr && okx01 && oky01);
+                // up the tree: the quad = a 32x32 block.  One add brings every lane ITS 2:1 PU (l = 0: + the quadrant to the
+                // right, 1: + the one below, 2: + the one above, 3: + the one to the left), a second the block
+                const uint32_t r32 = a + dpp<0x8d>(a);  // quad_perm [1,3,0,2]
+                paired(1, r32, idx, inr && okx32r && oky32r);
+                s32[q] = r32 + dpp<0x1b>(r32);          // quad_perm [3,2,1,0]: the other half of the block
+            }
+            // From the block upwards the sums repeat over the lanes of a quad, so lane l follows them for dx = dxb + l only
+            // (the winners meet across the quad at the end).  Same l = same dx in every quad of the row: the adds across
+            // quads stay single values.
+            {
+                const uint32_t sl = l == 0 ? s32[0] : l == 1 ? s32[1] : l == 2 ? s32[2] : s32[3];
+                const int dx = dxb + l;
+                const bool inr = valid && (unsigned)(dx + R) <= (unsigned)(2 * R);
+                const uint32_t idx = idxrow + (uint32_t)dx;
+                bool okx32 = true, okx64r = true, okx64 = true;
+                if constexpr (BORDER) {
                     okx32 = (unsigned)(cx + 32 * K + dx) <= (unsigned)(W - 32);
                     okx64r = (unsigned)(cx + ox64r + dx) <= (unsigned)(W - w64r);
                     okx64 = (unsigned)(cx + dx) <= (unsigned)(W - 64);
                 }
-                auto keyed = [&](uint32_t &best, uint32_t sad, bool ok) {
-                    const uint32_t key = (sad << IDXB) + idx;
-                    best = min(best, ok ? key : 0xffffffffu);
-                };
-                // a lane meets its candidates in raster order: strict < keeps the first
-                auto paired = [&](int i, uint32_t sad, bool ok) {
-                    if (ok && sad < bs[i]) {
-                        bs[i] = sad;
-                        bi[i] = idx;
-                    }
-                };
-                keyed(k8[0], fld(acc[0][0]), inr && okx0 && oky0);
-                keyed(k8[1], fld(acc[0][1]), inr && okx1 && oky0);
-                keyed(k8[2], fld(acc[1][0]), inr && okx0 && oky1);
-                keyed(k8[3], fld(acc[1][1]), inr && okx1 && oky1);
-                keyed(k168[0], fld(h8[0]), inr && okx01 && oky0);
-                keyed(k168[1], fld(h8[1]), inr && okx01 && oky1);
-                keyed(k816[0], fld(v8[0]), inr && okx0 && oky01);
-                keyed(k816[1], fld(v8[1]), inr && okx1 && oky01);
-                const uint32_t a = fld(s16);
-                if constexpr (kKey16)
-                    keyed(k16, a, inr && okx01 && oky01);
-                else
-                    paired(0, a, inr && okx01 && oky01);
-                // up the tree: the quad = a 32x32 block, the row of 16 lanes = the CTU
-                const uint32_t h32 = a + dpp<0xb1>(a);       // + horizontal neighbour (quad_perm [1,0,3,2])
-                const uint32_t v32 = a + dpp<0x4e>(a);       // + vertical neighbour   (quad_perm [2,3,0,1])
-                const uint32_t s32 = h32 + dpp<0x4e>(h32);   // the block
-                const uint32_t h64 = s32 + dpp<0x141>(s32);  // + the block beside it (row_half_mirror: quads 0 <-> 1, 2 <-> 3)
-                const uint32_t v64 = s32 + dpp<0x128>(s32);  // + the block below / above (row_ror:8: quads 0 <-> 2, 1 <-> 3)
-                const uint32_t s64 = h64 + dpp<0x128>(h64);  // the CTU
-                paired(1, hor32 ? h32 : v32, inr && okx32r && oky32r);
-                paired(2, s32, inr && okx32 && oky32);
-                paired(3, hor64 ? h64 : v64, inr && okx64r && oky64r);
-                paired(4, s64, inr && okx64 && oky64);
+                const uint32_t v64 = sl + dpp<0x128>(sl);   // row_ror:8: + the block below / above
+                const uint32_t hp = sl + dpp<0x124>(sl);    // row_ror:4: + the block of the quad before (right for Q = 1, 3)
+                const uint32_t hn = sl + dpp<0x12c>(sl);    // row_ror:12: + the block of the quad after (right for Q = 0, 2)
+                const uint32_t s64 = v64 + dpp<0x124>(v64); // left column + right column, whichever the lane holds
+                const uint32_t r64 = Q == 0 ? hn : Q == 3 ? hp : v64;  // upper 64x32, lower 64x32, 32x64 right (Q = 1) / left (Q = 2)
+                paired(2, sl, idx, inr && okx32 && oky32);
+                paired(3, r64, idx, inr && okx64r && oky64r);
+                paired(4, s64, idx, inr && okx64 && oky64);
             }
             gx += 16;
             while (gx >= ngx) {
@@ -218,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void me_pu_kernel(const uint8_t *__restrict
     // ---- winners: 64-bit key (sad << 32 | raster index) across the four rows of a wave, then across the four waves ----
     unsigned long long key[kLanePUs];
     auto unkey = [&](uint32_t k) -> unsigned long long {
-        return k == 0xffffffffu ? ~0ull : ((unsigned long long)(k >> IDXB) << 32) | (k & ((1u << IDXB) - 1u));
+        const bool none = kKeyPk ? (k >> 16) == 0xffffu : k == 0xffffffffu;
+        return none ? ~0ull : ((unsigned long long)(k >> IDXB) << 32) | (k & ((1u << IDXB) - 1u));
     };
 #pragma unroll
     for (int i = 0; i < 4; i++) key[i] = unkey(k8[i]);
@@ -242,9 +271,14 @@ __global__ __launch_bounds__(256, 2) void me_pu_kernel(const uint8_t *__restrict
     __syncthreads();
     if (tid < 16 * kLanePUs) {
         const int r = tid / kLanePUs, p = tid - r * kLanePUs;
-        unsigned long long k = wbest[0][r][p];
-        for (int w = 1; w < 4; w++) k = wbest[w][r][p] < k ? wbest[w][r][p] : k;
         const int Qr = r >> 2, lr = r & 3, Jr = Qr >> 1, Kr = Qr & 1;
+        unsigned long long k = ~0ull;
+        const int lanes = p >= 10 ? 4 : 1;  // from the block upwards the four lanes of a quad each followed one dx in four
+        for (int w = 0; w < 4; w++)
+            for (int i = 0; i < lanes; i++) {
+                const unsigned long long o = wbest[w][lanes == 4 ? 4 * Qr + i : r][p];
+                k = o < k ? o : k;
+            }
         const int jr = 2 * Jr + (lr >> 1), kr = 2 * Kr + (lr & 1);
         int s, X, Y;
         bool write = true;
@@ -289,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void me_pu_kernel(const uint8_t *__restrict
 
 int me_pu_device_setup(DeviceState &ds)
 {
-    int rc = allow_full_lds((const void *)me_pu_kernel<15>, ds);
+    int rc = allow_full_lds((const void *)me_pu_kernel<16>, ds);
     if (rc != X265AMD_OK) return rc;
     return allow_full_lds((const void *)me_pu_kernel<17>, ds);
 }
@@ -335,8 +369,8 @@ extern "C" int x265amd_me_fullsearch_pu_all(const uint8_t *d_cur, const uint8_t 
     g.ref_rs = ref_ref_stride;
     const dim3 grid(g.ctus_x, g.ctus_y, (unsigned)(nframes * nrefs));
     const int span = 2 * range + 1;
-    if (span * span <= (1 << 15))
-        hipLaunchKernelGGL(me_pu_kernel<15>, grid, dim3(256), lds, (hipStream_t)stream, d_cur, d_ref, out, g, pitch);
+    if (span * span <= (1 << 16))
+        hipLaunchKernelGGL(me_pu_kernel<16>, grid, dim3(256), lds, (hipStream_t)stream, d_cur, d_ref, out, g, pitch);
     else
         hipLaunchKernelGGL(me_pu_kernel<17>, grid, dim3(256), lds, (hipStream_t)stream, d_cur, d_ref, out, g, pitch);
     return hip_status(hipGetLastError());
