@@ -14,10 +14,11 @@
 //   4 rows x 4 waves   = 16 tasks in flight per step
 //
 // A lane owns the nine PUs inside its quadrant (four 8x8, two 16x8, two 8x16, the 16x16; sums on the packed u16
-// quadruples, winners as single-dword keys sad << IDXB | raster index under v_min_u32).  Above that, DPP adds
-// inside the quad give 32x16 / 16x32 / 32x32 and across quads 64x32 / 32x64 / 64x64; each lane tracks ONE 2:1 PU of
-// its 32x32 block, the block, ONE 2:1 PU of the CTU and the CTU (which one: by its position, see `role`), 13 PUs a
-// lane.  Every PU keeps its winner under its OWN legality (the window is staged unclipped, zeros outside the
+// quadruples, winners as single-dword keys sad << IDXB | raster index under v_min_u32; with 16 index bits the key is
+// the SAD's own field of the packed sums over the index, one instruction).  Above that, DPP adds inside the quad give
+// 32x16 / 16x32 / 32x32 and across quads 64x32 / 32x64 / 64x64; each lane tracks ONE 2:1 PU of its 32x32 block, the
+// block, ONE 2:1 PU of the CTU and the CTU (which one: by its position), 13 PUs a lane -- the last three for one dx in
+// four only (dx = l mod 4: these sums repeat over the lanes of a quad, and the winners meet at the end).  Every PU keeps its winner under its OWN legality (the window is staged unclipped, zeros outside the
 // picture) with the reference's argmin idiom: first strict minimum in raster order (src/encode.cpp:725-727,
 // 762-765).  Every output entry equals what the plain exhaustive search returns for blocks of that shape tiling
 // the picture -- that is the parity test (oracle: orc_me_fullsearch_wh / the reference's xSadN through
