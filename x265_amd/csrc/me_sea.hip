@@ -155,7 +155,8 @@ __device__ __forceinline__ int lb_bin(uint32_t lb)
 // chain steps of S rows that a lane may walk (a multiple of 5, the rotation period of its band registers):
 // ndy <= 257 (R <= 128) needs 17 at S = 16 and 33 at S = 8
 __host__ __device__ constexpr int sea_max_chain(int S) { return S == 16 ? 20 : 35; }
-constexpr int kBoundsThreads = 512;  // 8 waves, 4 workgroups per CU
+constexpr int kBoundsThreads = 512;  // 8 waves, 4 workgroups per CU; blocks of 32 with a first batch of 256: 4 waves, 8 workgroups
+                                     // (a +-64 window has 8 x 33 = 264 chains there: half of 512 threads would walk none)
 constexpr uint32_t kIllegal = 1u << 30;  // > any bound (16 * 65280)
 // the search geometry of one launch: the kernels are instantiated for blocks of 64 (sub-blocks of 16) and of 32 (8)
 constexpr uint32_t kNone = 0xffffu;  // stored bound: no legal member, or already scheduled
@@ -183,8 +184,8 @@ __device__ __forceinline__ int sea_class(int est) { return est >= 2048 ? 0 : est
 //   out: gl[plane][ctu][max_groups] u16 bound per group (kNone where scheduled / illegal),
 //        list0[plane][ctu][..] the first batch (the `nfirst` groups of the lowest histogram bins), hdr
 // ---------------------------------------------------------------------------------------------
-template <int B>
-__global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
+template <int B, int NT>
+__global__ __launch_bounds__(NT, 8) void sea_bounds_kernel(const uint8_t *__restrict__ cur_base,
                                                                    const uint8_t *__restrict__ ref_base,
                                                                  const uint32_t *__restrict__ pbuf,
                                                                  uint16_t *__restrict__ gl, uint16_t *__restrict__ list0,
@@ -264,9 +265,9 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
         const int nchain = S * L.ngx;  // (c, gx)
         // whole sweeps of chains; a short remainder (the 33rd column of groups of a +-64 window: 16 of
         // 528 chains) is done group by group below instead of costing a second walk
-        int nwalk = nchain - nchain % kBoundsThreads;
-        if (nchain - nwalk >= kBoundsThreads / 4) nwalk = nchain;
-        for (int t = tid; t < nwalk; t += kBoundsThreads) {
+        int nwalk = nchain - nchain % NT;
+        if (nchain - nwalk >= NT / 4) nwalk = nchain;
+        for (int t = tid; t < nwalk; t += NT) {
             const int c = t / L.ngx, gx = t - c * L.ngx;
             if (c >= L.ndy) continue;
             const uint32_t *pp = P + (int64_t)(cy + L.dylo + c) * g.width + L.wx0 + 4 * gx;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
         // remainder chains, one group per lane: item i = (step m, chain r)
         const int nrem = nchain - nwalk;
         const int nsteps = (L.ndy + S - 1) / S;
-        for (int i = tid; i < nrem * nsteps; i += kBoundsThreads) {
+        for (int i = tid; i < nrem * nsteps; i += NT) {
             const int m = i / nrem, t = nwalk + (i - m * nrem);
             const int c = t / L.ngx, gx = t - c * L.ngx;
             const int dyi = c + S * m;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
         // its groups under the pick bin and in it, one wave scan and one atomic per counter and wave hand out the slots,
         // then the lanes go over their groups again and take them.  (A ballot, two atomics and their round trips per sweep
         // made this selection as expensive as the bounds themselves -- half of the kernel at +-128.)
-        constexpr int kSweep = kBoundsThreads - 64;
+        constexpr int kSweep = NT - 64;
         uint32_t cnt = 0;  // groups under the pick bin | groups in it << 16  (at most 74 sweeps: the sums fit 16 bits)
         for (int gi = wtid; gi < L.ngroups; gi += kSweep) {
             const uint32_t v = (uint32_t)glb[gi];
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(kBoundsThreads, 8) void sea_bounds_kernel(const uin
     if (lane == 0 && rest_min != kNone) atomicMin(&rest_lb, rest_min);
     __syncthreads();
     // (what lies past a block's last group in its last 16 bytes is never looked at: kernel 2 checks the index)
-    for (int vi = tid; vi < nvec; vi += kBoundsThreads) reinterpret_cast<uint4 *>(glo)[vi] = reinterpret_cast<const uint4 *>(glb)[vi];
+    for (int vi = tid; vi < nvec; vi += NT) reinterpret_cast<uint4 *>(glo)[vi] = reinterpret_cast<const uint4 *>(glb)[vi];
     // ---- order the first batch for kernel 2's LDS reads: a lane there reads window dwords
     //      (dyi + row) * pitch + gx + k, so the 32 lanes of a half wave collide whenever their
     //      dyi * pitch + gx agree mod 32.  Deal the entries out bank by bank (rank within the bank first,
@@ -1275,10 +1276,11 @@ static __device__ __align__(256) unsigned char sea_scratch[kSeaStaticBytes];
 
 int me_sea_device_setup(DeviceState &ds)
 {
-    const void *fns[] = {(const void *)sea_bounds_kernel<64>, (const void *)sea_exact_kernel<false, 8, 64>,
+    const void *fns[] = {(const void *)sea_bounds_kernel<64, kBoundsThreads>, (const void *)sea_exact_kernel<false, 8, 64>,
                          (const void *)sea_exact_kernel<true, 8, 64>, (const void *)sea_exact_kernel<false, 16, 64>,
                          (const void *)sea_exact_kernel<true, 16, 64>,
-                         (const void *)sea_bounds_kernel<32>, (const void *)sea_exact_kernel<false, 8, 32>,
+                         (const void *)sea_bounds_kernel<32, kBoundsThreads>, (const void *)sea_bounds_kernel<32, 256>,
+                         (const void *)sea_exact_kernel<false, 8, 32>,
                          (const void *)sea_exact_kernel<true, 8, 32>, (const void *)sea_exact_kernel<false, 16, 32>,
                          (const void *)sea_exact_kernel<true, 16, 32>, (const void *)me_list_qsad<64>, (const void *)me_list_qsad<32>};
     for (const void *fn : fns) {
@@ -1511,12 +1513,17 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
     g.cur_fs = cur_frame_stride;
     g.ref_fs = ref_frame_stride;
     g.ref_rs = ref_ref_stride;
+    const int nfirst = waves16 ? 512 : 256;  // one half round of kernel 2's shape; kernel 1 deals it a thread per entry
+    const dim3 bgrid((unsigned)((total + 7) & ~7));
     if (ctu == 64)
-        hipLaunchKernelGGL(sea_bounds_kernel<64>, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
-                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, waves16 ? 512 : 256, bounds_stats);
+        hipLaunchKernelGGL((sea_bounds_kernel<64, kBoundsThreads>), bgrid, dim3(kBoundsThreads), lds_bounds, st, d_cur, d_ref, pbuf, gl, list0,
+                           hdr, order, ctrl, g, gl_pitch, (int)nplanes, nfirst, bounds_stats);
+    else if (nfirst <= 256)
+        hipLaunchKernelGGL((sea_bounds_kernel<32, 256>), bgrid, dim3(256), lds_bounds, st, d_cur, d_ref, pbuf, gl, list0, hdr, order, ctrl,
+                           g, gl_pitch, (int)nplanes, nfirst, bounds_stats);
     else
-        hipLaunchKernelGGL(sea_bounds_kernel<32>, dim3((unsigned)((total + 7) & ~7)), dim3(kBoundsThreads), lds_bounds, st, d_cur,
-                           d_ref, pbuf, gl, list0, hdr, order, ctrl, g, gl_pitch, (int)nplanes, waves16 ? 512 : 256, bounds_stats);
+        hipLaunchKernelGGL((sea_bounds_kernel<32, kBoundsThreads>), bgrid, dim3(kBoundsThreads), lds_bounds, st, d_cur, d_ref, pbuf, gl, list0,
+                           hdr, order, ctrl, g, gl_pitch, (int)nplanes, nfirst, bounds_stats);
     if (timing) (void)hipEventRecord(g_me_ev[3], st);
     uint16_t *wg_list = (uint16_t *)(ws + 256);
     int status;
