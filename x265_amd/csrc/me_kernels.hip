@@ -146,8 +146,9 @@ __global__ __launch_bounds__(256, 2) void me_fullsearch_qsad(const uint8_t *__re
                                                              x265amd_mv *__restrict__ out, const MeGeom g)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const int ctx = blockIdx.x, cty = blockIdx.y;
-    const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
+    int ctx, cty, z;
+    me_xcd_block(ctx, cty, z);
+    const int f = z / g.nrefs, rr = z - f * g.nrefs;
     const unsigned long long best = me_qsad_block<B>(smem, cur_base + f * g.cur_fs, ref_base + f * g.ref_fs + rr * g.ref_rs, g,
                                                      ctx * B, cty * B, 0, 1);
     if (threadIdx.x == 0)

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(256, 2) void me_pu_kernel(const uint8_t *__restrict
     const int Q = r16 >> 2, l = r16 & 3;
     const int J = Q >> 1, K = Q & 1;
     const int jq = 2 * J + (l >> 1), kq = 2 * K + (l & 1);  // the lane's quadrant: rows 16 jq .., columns 16 kq ..
-    const int ctx = blockIdx.x, cty = blockIdx.y;
-    const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
+    int ctx, cty, bz;
+    me_xcd_block(ctx, cty, bz);
+    const int f = bz / g.nrefs, rr = bz - f * g.nrefs;
     const int cx = ctx * 64, cy = cty * 64;
     const int R = g.range, span = 2 * R + 1;
     const int W = g.width, H = g.height;

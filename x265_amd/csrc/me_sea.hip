@@ -171,6 +171,7 @@ struct SeaHdr {  // per (plane, CTU)
     uint32_t probe_sad;  // the probe's best candidate: its exact SAD and raster index -- where kernel 2's search starts
     uint32_t probe_idx;  // (0xffffffff / 0xffffffff: no probe)
 };
+constexpr uint32_t kRouted = 0xffffffffu;  // SeaHdr::n0_rest of a block on the every-candidate list (n0 <= kFirstMax otherwise)
 constexpr int kFirstMax = 512;  // first batch = ONE half round of kernel 2: 256 groups for its 8-wave shape, 512 for the 16-wave one
 constexpr int kMaxWgLists = 512;  // persistent workgroups that may need a schedule slice in the workspace
 constexpr int kClasses = 4;   // launch-order classes of the work estimate, heaviest first
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(NT, 8) void sea_bounds_kernel(const uint8_t *__rest
             stats[16 * ctu_id + 13] = (uint32_t)(clock64() - tb3);  //         write-out
         }
         if (route) {
+            hdr[ctu_id].n0_rest = kRouted;  // (kernel 2 never sees this block: it is in none of its queues)
             unsigned long long *bk = reinterpret_cast<unsigned long long *>(glo);  // the block's row of bounds is free: merge key + count
             bk[0] = ~0ull;
             reinterpret_cast<uint32_t *>(glo)[2] = 0u;
@@ -1236,15 +1238,26 @@ template <int B>
 __global__ __launch_bounds__(256, 2) void me_list_qsad(const uint8_t *__restrict__ cur_base, const uint8_t *__restrict__ ref_base,
                                                        x265amd_mv *__restrict__ out, const MeGeom g,
                                                        const uint32_t *__restrict__ blist, const uint32_t *__restrict__ ctrl,
-                                                       uint16_t *__restrict__ gl, int gl_pitch)
+                                                       uint16_t *__restrict__ gl, int gl_pitch, const SeaHdr *__restrict__ hdr)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int n = (int)ctrl[kClasses + 1];
     if (n == 0) return;  // grid-uniform
     const int nsl = min((int)gridDim.x / n, 8);  // >= 1: the grid has a workgroup per block
-    const int item = blockIdx.x;
-    if (item >= n * nsl) return;  // block-uniform
-    const int ctu = (int)blist[item / nsl], slice = item % nsl;
+    int ctu, slice = 0;
+    if (nsl == 1) {
+        // More than half of the blocks are listed: a workgroup per BLOCK, in the XCD-aware order of the other kernels (XCD k
+        // takes the k-th contiguous eighth of the blocks: neighbours share most of their windows, and the list's own order
+        // -- the order in which kernel 1's workgroups finished -- scatters them over the L2s), the unlisted ones exit.
+        const int total = (int)gridDim.x, lin = (int)blockIdx.x;
+        const int xcd = lin & 7, slot = lin >> 3, base = total >> 3, rem = total & 7;
+        ctu = xcd * base + min(xcd, rem) + slot;
+        if (hdr[ctu].n0_rest != kRouted) return;  // block-uniform
+    } else {
+        const int item = blockIdx.x;
+        if (item >= n * nsl) return;  // block-uniform
+        ctu = (int)blist[item / nsl], slice = item % nsl;
+    }
     const int per_plane = g.ctus_x * g.ctus_y;
     const int plane = ctu / per_plane, cin = ctu - plane * per_plane;
     const int cty = cin / g.ctus_x, ctx = cin - cty * g.ctus_x;
@@ -1552,9 +1565,9 @@ static int sea_search(DeviceState &ds, const uint8_t *d_cur, const uint8_t *d_re
         const dim3 grid3((unsigned)total);
         const uint32_t *blist = order + (size_t)kClasses * total;
         if (ctu == 64)
-            hipLaunchKernelGGL(me_list_qsad<64>, grid3, dim3(256), lds3, st, d_cur, d_ref, d_out, g, blist, ctrl, gl, gl_pitch);
+            hipLaunchKernelGGL(me_list_qsad<64>, grid3, dim3(256), lds3, st, d_cur, d_ref, d_out, g, blist, ctrl, gl, gl_pitch, hdr);
         else
-            hipLaunchKernelGGL(me_list_qsad<32>, grid3, dim3(256), lds3, st, d_cur, d_ref, d_out, g, blist, ctrl, gl, gl_pitch);
+            hipLaunchKernelGGL(me_list_qsad<32>, grid3, dim3(256), lds3, st, d_cur, d_ref, d_out, g, blist, ctrl, gl, gl_pitch, hdr);
     }
     if (timing) (void)hipEventRecord(g_me_ev[4], st);
     return hip_status(hipGetLastError());

@@ -27,8 +27,9 @@ __global__ __launch_bounds__(256, 2) void me_tree_kernel(const uint8_t *__restri
     __shared__ unsigned long long wbest[4][kTreePUs];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ctx = blockIdx.x, cty = blockIdx.y;
-    const int f = blockIdx.z / g.nrefs, rr = blockIdx.z - f * g.nrefs;
+    int ctx, cty, bz;
+    me_xcd_block(ctx, cty, bz);
+    const int f = bz / g.nrefs, rr = bz - f * g.nrefs;
     const int cx = ctx * 64, cy = cty * 64;
     const int R = g.range, span = 2 * R + 1;
     const uint8_t *cur = cur_base + f * g.cur_fs;
