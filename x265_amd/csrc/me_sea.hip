@@ -151,6 +151,16 @@ __device__ __forceinline__ int lb_bin(uint32_t lb)
     const int e = (int)(__float_as_uint((float)lb) >> 21) - 507;
     return e < 0 ? 0 : e;
 }
+// The smallest stored bound of bin `bin` or of a later one (bins that no integer reaches are empty): lb_bin(v) < bin  <=>
+// v < lb_bin_first(bin).  0 for bin <= 0; kNone (0xffff, above every stored bound) from kBins on.
+__device__ __forceinline__ uint32_t lb_bin_first(int bin)
+{
+    if (bin <= 0) return 0u;
+    if (bin >= kBins) return 0xffffu;
+    const float f = __uint_as_float((uint32_t)(bin + 507) << 21);  // the float whose bits open the bin: >= 1, below 2^24
+    const uint32_t v = (uint32_t)f;
+    return min(v + ((float)v < f ? 1u : 0u), 0xffffu);  // its ceiling
+}
 
 // chain steps of S rows that a lane may walk (a multiple of 5, the rotation period of its band registers):
 // ndy <= 257 (R <= 128) needs 17 at S = 16 and 33 at S = 8
@@ -454,13 +464,13 @@ __global__ __launch_bounds__(NT, 8) void sea_bounds_kernel(const uint8_t *__rest
         // then the lanes go over their groups again and take them.  (A ballot, two atomics and their round trips per sweep
         // made this selection as expensive as the bounds themselves -- half of the kernel at +-128.)
         constexpr int kSweep = NT - 64;
+        // the bin is monotone in the bound: "under the pick bin" and "in it" are two comparisons with the smallest bounds of
+        // bins pb and pb + 1 (kNone = 0xffff is under neither; pb == kBins: every legal group is under it)
+        const uint32_t t0 = lb_bin_first(pb), t1 = lb_bin_first(pb + 1);
         uint32_t cnt = 0;  // groups under the pick bin | groups in it << 16  (at most 74 sweeps: the sums fit 16 bits)
         for (int gi = wtid; gi < L.ngroups; gi += kSweep) {
             const uint32_t v = (uint32_t)glb[gi];
-            if (v != kNone) {
-                const int bin = lb_bin(v);
-                cnt += (bin < pb ? 1u : 0u) + (bin == pb ? 0x10000u : 0u);  // pb == kBins: every legal group is under it
-            }
+            cnt += (v < t0 ? 1u : 0u) + ((v >= t0 && v < t1) ? 0x10000u : 0u);
         }
         const uint32_t inc = me_wave_scan_u32(cnt, lane), tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         int wl = 0, we = 0;
@@ -472,9 +482,7 @@ __global__ __launch_bounds__(NT, 8) void sea_bounds_kernel(const uint8_t *__rest
         int se = __builtin_amdgcn_readfirstlane(we) + (int)((inc - cnt) >> 16);      // its next rank within bin pb
         for (int gi = wtid; gi < L.ngroups; gi += kSweep) {
             const uint32_t v = (uint32_t)glb[gi];
-            if (v == kNone) continue;
-            const int bin = lb_bin(v);
-            const bool below = bin < pb, equal = bin == pb;
+            const bool below = v < t0, equal = v >= t0 && v < t1;  // (kNone: neither, and it leaves rest_min as it is)
             const bool take = below || (equal && se < quota);
             const int slot = equal ? nbelow + se : sl;
             sl += below ? 1 : 0;
