@@ -295,16 +295,18 @@ __global__ __launch_bounds__(NT, 8) void sea_bounds_kernel(const uint8_t *__rest
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int kp = 0; kp < 2; kp++) bnd[j][kp] = *reinterpret_cast<const uint4 *>(pp + j * band + 2 * S * kp);
+            const uint32_t *ppre = pp + 3 * band;  // the band loaded last
             for (int m0 = 0; m0 < sea_max_chain(S); m0 += 5)  // unrolled by the rotation period: static register indices
 #pragma unroll
                 for (int mm = 0; mm < 5; mm++) {
                     const int m = m0 + mm;
                     const int dyi = c + S * m;
                     if (dyi >= L.ndy) break;
-                    if (dyi + S < L.ndy) {
+                    {   // always in flight behind the step's sums: a load under a condition makes the compiler wait for it at
+                        // once (both paths must be safe).  The chain's last step reloads the band before.
+                        ppre += dyi + S < L.ndy ? band : 0;
 #pragma unroll
-                        for (int kp = 0; kp < 2; kp++)
-                            bnd[(mm + 4) % 5][kp] = *reinterpret_cast<const uint4 *>(pp + (m + 4) * band + 2 * S * kp);
+                        for (int kp = 0; kp < 2; kp++) bnd[(mm + 4) % 5][kp] = *reinterpret_cast<const uint4 *>(ppre + 2 * S * kp);
                     }
                     uint32_t lb[4] = {lb0[0], lb0[1], lb0[2], lb0[3]};
 #pragma unroll
