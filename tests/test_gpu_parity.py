@@ -315,6 +315,27 @@ def test_me_sea_equals_exhaustive_on_hostile_content(gpu):
             np.testing.assert_array_equal(x, y, f"ctu {ctu} range {r}")
 
 
+@pytest.mark.parametrize("noise_rows", [1, 3, 5, 7, 8])
+def test_me_sea_partly_unprunable_pictures(gpu, noise_rows):
+    """Pictures of which a part is white noise (those blocks go to the every-candidate list of the elimination search) and
+    the rest is content that moves.  A few listed blocks are cut into slices (1 and 3 rows of 8: eight and two slices a
+    block); when more than half of the blocks are listed (5, 7, 8 rows) they are taken block by block in the XCD-aware
+    order and the unlisted ones skipped.  Every share must give what the every-candidate kernel gives."""
+    from x265_amd import synth
+    rng = np.random.default_rng(40 + noise_rows)
+    h, w, r = 512, 576, 32
+    seq = synth.make_sequence(w, h, 3, search_range=r, seed=70 + noise_rows)
+    cur = np.stack([seq[1], seq[2]]).copy()
+    ref = np.stack([seq[0], seq[1]]).copy()
+    for f in range(2):
+        cur[f, :64 * noise_rows] = rng.integers(0, 256, (64 * noise_rows, w), dtype=np.uint8)
+        ref[f, :64 * noise_rows] = rng.integers(0, 256, (64 * noise_rows, w), dtype=np.uint8)
+    for ctu in (64, 32):
+        x = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, r, method="brute"))
+        y = gpu.mv_to_numpy(gpu.me_fullsearch(dev(cur), dev(ref), ctu, r, method="sea"))
+        np.testing.assert_array_equal(x, y, f"ctu {ctu}")
+
+
 def test_me_argument_errors(gpu):
     a = torch.zeros((128, 128), dtype=torch.uint8, device="cuda")
     with pytest.raises(gpu.X265AmdError):
